@@ -1,0 +1,220 @@
+"""ORACLE — test infrastructure only.  ctypes bindings for oracle/_build/liboracle.so."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, "_build")
+REFOUT = os.path.join(HERE, "_ref")
+
+GAME_DTYPE = np.dtype([
+    ("rows", "<u2", (20,)), ("piece", "u1"), ("rot", "u1"), ("x", "i1"), ("y", "i1"),
+    ("drop_ctr", "u1"), ("flags", "u1"), ("combo", "<i2"), ("piece_count", "<u4"), ("seed", "<u4"),
+    ("score", "<i4"), ("line_clears", "<i4")])
+OBS_DTYPE = np.dtype([("rows", "<u2", (20,)), ("cells", "u1", (4,)), ("end", "u1"), ("pad", "u1", (3,))])
+assert GAME_DTYPE.itemsize == 64 and OBS_DTYPE.itemsize == 48
+
+EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+
+
+def build(ref=True):
+    """Compile the oracle (and, when /root/reference exists, the reference's own native sources)."""
+    targets = ["own"] + (["ref"] if ref else [])
+    subprocess.check_call(["make", "-s", "-C", HERE] + targets)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(BUILD, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=os.path.isdir("/root/reference"))
+        L = C.CDLL(path)
+        vp, i32, f64, u32 = C.c_void_p, C.c_int, C.c_double, C.c_uint32
+        L.orc_agent_new.restype = vp
+        L.orc_agent_new.argtypes = [i32, i32, i32, i32, i32, f64, i32, i32, i32, i32, i32, vp, vp]
+        L.orc_agent_free.argtypes = [vp]
+        L.orc_agent_update_root.argtypes = [vp, vp]
+        L.orc_agent_play.argtypes = [vp, i32]
+        L.orc_agent_play.restype = i32
+        L.orc_agent_compute_stats.argtypes = [vp, i32, vp]
+        for name in ("child", "score", "n_to_o", "visit", "value", "variance", "end_obs", "obs_state", "games",
+                     "stats", "mem_state", "mem_value", "mem_variance", "mem_visit", "rng"):
+            f = getattr(L, "orc_agent_" + name)
+            f.restype, f.argtypes = vp, [vp]
+        for name in ("root", "episode", "error", "n_avail", "n_obs_avail", "memory_index"):
+            f = getattr(L, "orc_agent_" + name)
+            f.restype, f.argtypes = i32, [vp]
+        for name in ("n_sims", "n_expand", "n_gc", "n_eval_states", "trace_len_sum"):
+            f = getattr(L, "orc_agent_" + name)
+            f.restype, f.argtypes = C.c_long, [vp]
+        L.orc_game_init.argtypes = [vp, i32, i32, i32, u32]
+        L.orc_game_play.argtypes = [vp, i32, i32, i32, i32, vp]
+        L.orc_game_reset.argtypes = [vp, i32, i32, i32, vp]
+        L.orc_game_render.argtypes = [vp, vp]
+        L.orc_game_pack_obs.argtypes = [vp, vp]
+        L.orc_obs_render.argtypes = [vp, vp]
+        L.orc_game_hash.restype = C.c_uint64
+        L.orc_game_hash.argtypes = [vp]
+        L.orc_obs_hash.restype = C.c_uint64
+        L.orc_obs_hash.argtypes = [vp]
+        L.orc_piece_at.argtypes = [u32, u32, i32]
+        L.orc_srand.argtypes = [vp, u32]
+        L.orc_rand.argtypes = [vp]
+        L.orc_rand.restype = i32
+        L.orc_norm_quantile.restype = f64
+        L.orc_norm_quantile.argtypes = [f64]
+        L.orc_exp.restype = f64
+        L.orc_exp.argtypes = [f64]
+        L.orc_get_unique_child_obs.argtypes = [i32, vp, vp, vp, vp, vp]
+        L.orc_select_trace_obs.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32]
+        L.orc_backup_trace_obs.argtypes = [vp, i32, vp, vp, vp, vp, vp, f64, f64, f64]
+        L.orc_backup_trace_mixture_obs.argtypes = [vp, i32, vp, vp, vp, vp, vp, f64, f64, f64]
+        L.orc_backup_trace_obs_LP.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, f64, i32, i32]
+        L.orc_backup_obs_cppagent.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, f64, C.c_float]
+        L.orc_get_all_childs.argtypes = [i32, vp, i32, vp]
+        L.orc_valuenet_forward.argtypes = [vp, vp, i32, vp, vp]
+        L.orc_hash_eval.argtypes = [vp, vp, i32, vp, vp]
+        _lib = L
+    return _lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Game:
+    """One oracle environment (ENGINE_SPEC.md) driven through liboracle."""
+
+    def __init__(self, app=1, scoring=0, randomizer=0, seed=0):
+        self.cfg = (app, scoring, randomizer)
+        self.g = np.zeros(1, GAME_DTYPE)
+        self.line_stats = np.zeros(4, np.int32)
+        lib().orc_game_init(ptr(self.g), app, scoring, randomizer, seed)
+
+    def play(self, a):
+        lib().orc_game_play(ptr(self.g), *self.cfg, int(a), ptr(self.line_stats))
+
+    def reset(self):
+        lib().orc_game_reset(ptr(self.g), *self.cfg, ptr(self.line_stats))
+
+    def copy(self):
+        o = Game.__new__(Game)
+        o.cfg, o.g, o.line_stats = self.cfg, self.g.copy(), self.line_stats.copy()
+        return o
+
+    def getState(self):
+        out = np.zeros((20, 10), np.int8)
+        lib().orc_game_render(ptr(self.g), ptr(out))
+        return out
+
+    def packed_obs(self):
+        o = np.zeros(1, OBS_DTYPE)
+        lib().orc_game_pack_obs(ptr(self.g), ptr(o))
+        return o
+
+    end = property(lambda s: bool(s.g["flags"][0] & 1))
+    score = property(lambda s: int(s.g["score"][0]))
+    line_clears = property(lambda s: int(s.g["line_clears"][0]))
+    combo = property(lambda s: int(s.g["combo"][0]))
+
+
+class Agent:
+    """Oracle tree agent. kind: 0 ValueSim, 1 ValueSimLP, 2 all-C++ agent LP, 3 all-C++ agent single."""
+
+    def __init__(self, kind, max_nodes=100000, app=1, scoring=0, randomizer=0, gamma=0.999, low=1, benchmark=False,
+                 online=False, min_visits_to_store=None, memory_size=0, evaluator="hash", params=None):
+        L = lib()
+        self.L = L
+        if min_visits_to_store is None:
+            min_visits_to_store = {0: 10, 1: 25}.get(kind, 40)
+        self._keep = None
+        if evaluator == "hash":
+            fn, ctx = C.cast(L.orc_hash_eval, C.c_void_p), None
+        elif evaluator == "valuenet":
+            self._keep = np.ascontiguousarray(params, np.float32)
+            assert self._keep.size == 478342
+            fn, ctx = C.cast(L.orc_valuenet_eval, C.c_void_p), ptr(self._keep)
+        else:  # python callable(states int8 [k,20,10]) -> (v[k], var[k])
+            def _cb(_ctx, states, k, v, var):
+                s = np.ctypeslib.as_array(C.cast(states, C.POINTER(C.c_int8)), (k, 20, 10))
+                vv, vr = evaluator(s.copy())
+                np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_float)), (k,))[:] = np.asarray(vv, np.float32).ravel()
+                np.ctypeslib.as_array(C.cast(var, C.POINTER(C.c_float)), (k,))[:] = np.asarray(vr, np.float32).ravel()
+            self._keep = EVAL_FN(_cb)
+            fn, ctx = C.cast(self._keep, C.c_void_p), None
+        self.max_nodes = max_nodes
+        self.h = L.orc_agent_new(max_nodes, app, scoring, randomizer, kind, gamma, low, int(benchmark), int(online),
+                                 min_visits_to_store, memory_size, fn, ctx)
+
+    def update_root(self, game):
+        self.L.orc_agent_update_root(self.h, ptr(game.g))
+
+    def play(self, sims):
+        return self.L.orc_agent_play(self.h, sims)
+
+    def _arr(self, name, dtype, shape):
+        p = getattr(self.L, "orc_agent_" + name)(self.h)
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        buf = (C.c_char * n).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def arrays(self):
+        n = self.max_nodes
+        return dict(child=self._arr("child", np.int32, (n, 7)), score=self._arr("score", np.float32, (n,)),
+                    n_to_o=self._arr("n_to_o", np.int32, (n,)), visit=self._arr("visit", np.int32, (n,)),
+                    value=self._arr("value", np.float32, (n,)), variance=self._arr("variance", np.float32, (n,)),
+                    end_obs=self._arr("end_obs", np.uint8, (n,)), obs_state=self._arr("obs_state", OBS_DTYPE, (n,)),
+                    games=self._arr("games", GAME_DTYPE, (n,)))
+
+    def stats(self):
+        return self._arr("stats", np.float32, (3, 7)).copy()
+
+    def memory(self):
+        m = self.L.orc_agent_memory_index(self.h)
+        if m == 0:
+            return (np.zeros((0, 200), np.int8), np.zeros(0, np.float32), np.zeros(0, np.float32),
+                    np.zeros(0, np.float32))
+        return (self._arr("mem_state", np.int8, (m, 200)).copy(), self._arr("mem_value", np.float32, (m,)).copy(),
+                self._arr("mem_variance", np.float32, (m,)).copy(), self._arr("mem_visit", np.float32, (m,)).copy())
+
+    def __getattr__(self, name):
+        if name in ("root", "episode", "error", "n_avail", "n_obs_avail", "memory_index", "n_sims", "n_expand",
+                    "n_gc", "n_eval_states", "trace_len_sum"):
+            return getattr(self.L, "orc_agent_" + name)(self.h)
+        raise AttributeError(name)
+
+    def close(self):
+        if self.h:
+            self.L.orc_agent_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_ref_native(name):
+    """Import the reference's own compiled module (oracle/_ref/<name>*.so): 'core' or 'agent'."""
+    import importlib.util
+    import sysconfig
+    if BUILD not in sys.path:
+        sys.path.insert(0, BUILD)  # the agent module needs `pyTetris` types registered
+    path = os.path.join(REFOUT, name + sysconfig.get_config_var("EXT_SUFFIX"))
+    if not os.path.exists(path):
+        return None
+    full = "agents.cppmodule." + name
+    if full in sys.modules:
+        return sys.modules[full]
+    spec = importlib.util.spec_from_file_location(full, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

@@ -1,0 +1,213 @@
+"""Generate tests/golden/*.json|npz from the REFERENCE ITSELF (run in the build container only).
+
+    python tests/golden/make_golden.py
+
+* ref_uct_*.npz      : seeded random DAGs pushed through the reference's own core.cpp (compiled in place
+                       into oracle/_ref/) -> expected traces / post-backup arrays / reachable sets.
+* ref_agent_*.json   : the reference's own Python agents (agents/ValueSim.py, ValueSimLP.py imported from
+                       /root/reference) playing on the oracle engine -> per-move (action, score, lines, stats).
+* ref_valuenet.npz   : the reference's own Net (model/model_vv.py) on CPU fp32 -> weights, inputs, outputs.
+* ref_norm_quantile.npy : special.h norm_quantile through the compiled reference (via policy_clt probing is
+                       not possible; the table is pinned through select traces instead) - see tests.
+The fixtures travel to the GPU box; /root/reference does not.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from oracle import binding as B  # noqa: E402
+from oracle import ref_shims  # noqa: E402
+
+
+def random_dag(rng, n_nodes, n_obs, expand_frac=0.6, low_visits=True):
+    """A layered DAG in the reference's array layout (agents/agent.py:58-88)."""
+    child = np.zeros((n_nodes, 7), np.int32)
+    order = np.arange(1, n_nodes)
+    for i in order:
+        if i < n_nodes - 8 and rng.random() < expand_frac:
+            lo = i + 1
+            hi = min(n_nodes, i + 40)
+            cs = rng.integers(lo, hi, 7)
+            cs[rng.random(7) < 0.15] = 0
+            if rng.random() < 0.3:
+                cs[rng.integers(0, 7)] = cs[rng.integers(0, 7)]
+            child[i] = cs
+    n_to_o = rng.integers(1, n_obs, n_nodes).astype(np.int32)
+    n_to_o[0] = 0
+    score = np.round(rng.random(n_nodes) * 50).astype(np.float32)
+    score[rng.random(n_nodes) < 0.3] = 7.0  # force score ties between duplicate observations
+    visit = rng.integers(0 if low_visits else 1, 30, n_obs).astype(np.int32)
+    value = (rng.standard_normal(n_obs) * 20).astype(np.float32)
+    variance = (rng.random(n_obs) * 300).astype(np.float32)
+    variance[rng.random(n_obs) < 0.1] = 0
+    return child, n_to_o, score, visit, value, variance
+
+
+def gen_uct():
+    ref_shims.install()
+    core = sys.modules["agents.cppmodule.core"]
+    rng = np.random.default_rng(20260925)
+    cases = {}
+    n_cases = 24
+    for ci in range(n_cases):
+        n_nodes, n_obs = 400, int(rng.integers(60, 300))
+        child, n_to_o, score, visit, value, variance = random_dag(rng, n_nodes, n_obs, low_visits=(ci % 2 == 0))
+        if ci == 3:  # the n == 1 NaN case: a single child observation visited once (special.h t=1)
+            child[1] = 0
+            child[1][2] = 5
+            visit[n_to_o[5]] = 1
+        low = [1, 5][ci % 3 == 2]
+        ref_shims.srand(1)
+        traces = []
+        v, val, var = visit.copy(), value.copy(), variance.copy()
+        uniq = []
+        for rep in range(12):
+            root = int(rng.integers(1, 60))
+            t = core.select_trace_obs(root, child, v, val, var, score, n_to_o, low)
+            traces.append(np.asarray(t, np.int32))
+            cn, co = core.get_unique_child_obs(root, child, score, n_to_o)
+            uniq.append((root, list(cn), list(co)))
+            mode = rep % 3
+            if mode == 0:
+                core.backup_trace_obs(t, v, val, var, n_to_o, score, float(rng.random() * 90), float(rng.random() * 500),
+                                      0.999)
+            else:
+                leaf = int(t[-1])
+                cn, co = core.get_unique_child_obs(leaf, child, score, n_to_o)
+                k = len(cn)
+                end = np.zeros(n_nodes, bool)
+                if mode == 2 and k:
+                    end[cn[0]] = True
+                _v = (rng.random(k) * 60).astype(np.float32)
+                _var = (rng.random(k) * 400).astype(np.float32)
+                core.backup_trace_obs_LP(t, v, val, var, n_to_o, score, end, list(cn), list(co), _v, _var, 0.999, False,
+                                         True)
+        reach = np.array(sorted(core.get_all_childs(int(rng.integers(1, 60)), child)), np.int32)
+        cases["c%d" % ci] = dict(child=child, n_to_o=n_to_o, score=score, visit0=visit, value0=value,
+                                 variance0=variance, low=low, traces=traces, uniq=uniq, visit1=v, value1=val,
+                                 variance1=var, reach=reach)
+    # flatten to npz: the generating seed is fixed, tests regenerate the inputs and only need the outputs
+    flat = {}
+    for name, c in cases.items():
+        flat[name + "_tracecat"] = np.concatenate(c["traces"])
+        flat[name + "_tracelen"] = np.array([len(t) for t in c["traces"]], np.int32)
+        flat[name + "_uniq"] = np.array([[r] + cn + [0] * (7 - len(cn)) + co + [0] * (7 - len(co)) + [len(cn)]
+                                         for r, cn, co in c["uniq"]], np.int32)
+        for k in ("visit1", "value1", "variance1", "reach"):
+            flat[name + "_" + k] = c[k]
+    np.savez_compressed(os.path.join(OUT, "ref_uct.npz"), **flat)
+    print("ref_uct.npz:", len(cases), "cases")
+
+
+def play_ref(name, sims, max_nodes, seed, max_moves, evaluator):
+    ref_shims.install()
+    from pyTetris import Tetris
+    ref_shims.srand(1)
+    agent = ref_shims.make_agent(name, sims, max_nodes=max_nodes, evaluator=evaluator)
+    game = Tetris((20, 10), 1, 0, 0, seed)
+    agent.update_root(game)
+    moves = []
+    while len(moves) < max_moves:
+        a = int(agent.play())
+        stats = agent.get_stats()
+        game.play(a)
+        agent.update_root(game)
+        moves.append([a, int(game.score), int(game.line_clears), stats.astype("<f4").tobytes().hex()])
+        if game.end:
+            game.reset()
+            agent.update_root(game)
+    return moves
+
+
+def hash_eval(states):
+    k = states.shape[0]
+    s = np.ascontiguousarray(states, np.int8)
+    v = np.zeros(k, np.float32)
+    var = np.zeros(k, np.float32)
+    B.lib().orc_hash_eval(None, B.ptr(s), k, B.ptr(v), B.ptr(var))
+    return v, var
+
+
+def gen_agents(params):
+    def net_eval(states):
+        k = states.shape[0]
+        s = np.ascontiguousarray(states, np.int8)
+        v = np.zeros(k, np.float32)
+        var = np.zeros(k, np.float32)
+        B.lib().orc_valuenet_forward(B.ptr(params), B.ptr(s), k, B.ptr(v), B.ptr(var))
+        return v, var
+    runs = [
+        dict(name="ValueSim", sims=40, max_nodes=8000, seed=11, max_moves=200, evaluator="hash"),
+        dict(name="ValueSimLP", sims=30, max_nodes=8000, seed=12, max_moves=200, evaluator="hash"),
+        dict(name="ValueSim", sims=25, max_nodes=100000, seed=13, max_moves=30, evaluator="valuenet"),
+        dict(name="ValueSimLP", sims=12, max_nodes=100000, seed=14, max_moves=24, evaluator="valuenet"),
+    ]
+    out = []
+    for r in runs:
+        ev = hash_eval if r["evaluator"] == "hash" else net_eval
+        moves = play_ref(r["name"], r["sims"], r["max_nodes"], r["seed"], r["max_moves"], ev)
+        out.append(dict(r, moves=moves))
+        print(r["name"], r["evaluator"], "moves", len(moves), "final score", moves[-1][1], "lines", moves[-1][2])
+    with open(os.path.join(OUT, "ref_agents.json"), "w") as f:
+        json.dump(out, f)
+
+
+def gen_valuenet():
+    """Weights + outputs of the reference's own Net (model/model_vv.py:13-52) on CPU fp32."""
+    ref_shims.install()
+    import torch
+    from model.model_vv import Net
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    net = Net().eval()
+    sd = net.state_dict()
+    order = ["head.conv1.weight", "head.conv1.bias", "head.conv2.weight", "head.conv2.bias", "head.conv3.weight",
+             "head.conv3.bias", "head.fc1.weight", "head.fc1.bias", "head.fc_out.weight", "head.fc_out.bias",
+             "out_ubound", "out_lbound"]
+    assert sorted(sd.keys()) == sorted(order), list(sd.keys())
+    params = np.concatenate([sd[k].detach().numpy().ravel() for k in order]).astype(np.float32)
+    assert params.size == 478342
+    # a second, "trained-like" parameter set with larger activations (stress for the 1e-4 tolerance)
+    rng = np.random.default_rng(7)
+    params2 = params.copy()
+    params2[:478338] *= 1.6
+    params2[478338:478340] = [250.0, 4000.0]
+    # inputs: boards in the style of tools/test.py:23-28 (random cells below a cleared top, one falling piece)
+    states = np.zeros((64, 20, 10), np.int8)
+    for i in range(64):
+        h = int(rng.integers(0, 16))
+        states[i, 20 - h:, :] = (rng.random((h, 10)) < 0.7).astype(np.int8)
+        states[i, 1:3, 5:7] = -1 if i % 4 else 0
+    outs = []
+    for p in (params, params2):
+        off = 0
+        with torch.no_grad():
+            for k in order:
+                n = sd[k].numel()
+                sd[k].copy_(torch.from_numpy(p[off:off + n].reshape(sd[k].shape)))
+                off += n
+            y = net(torch.from_numpy(states.astype(np.float32))[:, None]).numpy()
+        outs.append(y.astype(np.float32))
+    np.savez_compressed(os.path.join(OUT, "ref_valuenet.npz"), params=params, params2=params2, states=states,
+                        out=outs[0], out2=outs[1])
+    print("ref_valuenet.npz: out range", outs[0].min(0), outs[0].max(0), outs[1].min(0), outs[1].max(0))
+    return params
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["uct", "valuenet", "agents"]
+    params = None
+    if "uct" in which:
+        gen_uct()
+    if "valuenet" in which:
+        params = gen_valuenet()
+    if "agents" in which:
+        if params is None:
+            params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]
+        gen_agents(params)

@@ -1,0 +1,58 @@
+"""Pin oracle/agent_oracle.c against the reference's own Python agents.
+
+tests/golden/ref_agents.json was produced by agents/ValueSim.py and agents/ValueSimLP.py imported
+unmodified from /root/reference (tests/golden/make_golden.py): per move (action, score, lines, 3x7 stats
+bytes), across GC events (small pools) and episode resets.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+KIND = {"ValueSim": 0, "ValueSimLP": 1}
+
+
+def _runs(golden_dir):
+    with open(os.path.join(golden_dir, "ref_agents.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_agent_oracle_replays_reference(oracle, golden_dir, idx):
+    r = _runs(golden_dir)[idx]
+    params = np.load(os.path.join(golden_dir, "ref_valuenet.npz"))["params"]
+    g = oracle.Game(seed=r["seed"])
+    a = oracle.Agent(KIND[r["name"]], max_nodes=r["max_nodes"], evaluator=r["evaluator"], params=params)
+    a.update_root(g)
+    for i, (act, score, lines, stats_hex) in enumerate(r["moves"]):
+        got = a.play(r["sims"])
+        assert a.error == 0
+        assert got == act, (i, got, act)
+        assert a.stats().astype("<f4").tobytes().hex() == stats_hex, i
+        g.play(got)
+        a.update_root(g)
+        assert (g.score, g.line_clears) == (score, lines), i
+        if g.end:
+            g.reset()
+            a.update_root(g)
+    if r["max_nodes"] < 100000:
+        assert a.n_gc >= 1  # the fixture crosses at least one pool-exhaustion GC
+    a.close()
+
+
+def test_store_nodes_emits_replay_tuples(oracle):
+    g = oracle.Game(seed=21)
+    a = oracle.Agent(0, max_nodes=6000, online=True, memory_size=100000, min_visits_to_store=3)
+    a.update_root(g)
+    for _ in range(120):
+        g.play(a.play(40))
+        a.update_root(g)
+        if g.end:
+            g.reset()
+            a.update_root(g)
+    assert a.n_gc >= 1
+    st, val, var, vis = a.memory()
+    assert len(st) > 0 and (vis >= 3).all()
+    assert set(np.unique(st)) <= {-1, 0, 1}
+    a.close()
