@@ -1,0 +1,147 @@
+/*
+ * tetris_mcts_hip.h — C ABI of libtetris_mcts_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the reference's hot path:
+ *   - environment step            : pyTetris `Tetris.play/copy_from/getState/reset`
+ *                                   (call sites play.py:150,165; agents/agent.py:101-129,140-145)
+ *   - tree agent (select/expand/backup, transposition + observation tables)
+ *                                 : agents/cppmodule/agent.cpp TreeAgent/MCTSAgent (agent.cpp:84-568) and the
+ *                                   Python twins agents/agent.py:90-193, ValueSim.py:52-99, ValueSimLP.py:13-70
+ *   - the five `agents.cppmodule.core` functions (core.cpp:20-26) in batched form over device arrays
+ *   - leaf evaluator              : model/model_vv.py:13-52,210-217
+ * All pointers are DEVICE pointers unless named host_*.  Every function enqueues work on `stream`
+ * (a hipStream_t passed as void*) and returns a hipError_t value (0 = success); nothing synchronises.
+ * No torch types cross this boundary.  One process drives one GPU; games shard across processes.
+ */
+#ifndef TETRIS_MCTS_HIP_H
+#define TETRIS_MCTS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TM_NACT 7
+#define TM_GAME_DW 16      /* packed game, ENGINE_SPEC.md section 2 (64 bytes) */
+#define TM_OBS_DW 12       /* packed observation, ENGINE_SPEC.md section 7 (48 bytes) */
+#define TM_REC_DW 24       /* node record (96 bytes), see DESIGN.md "node store" */
+#define TM_GS_DW 16        /* per-game control block */
+#define TM_LEAF_DW 32      /* per-game leaf hand-off between the front and back halves of a simulation */
+#define TM_VALUENET_PARAMS 478342
+#define TM_VALUENET_SCRATCH 9728  /* floats of scratch per state for tm_valuenet_forward */
+
+/* per-game control block (int32 words) */
+enum {
+    TM_GS_ROOT = 0, TM_GS_EPISODE, TM_GS_NFREE_NODE, TM_GS_NFREE_OBS, TM_GS_TRACE_LEN, TM_GS_PENDING,
+    TM_GS_ERR, TM_GS_N_EXPAND, TM_GS_N_SIMS, TM_GS_N_GC, TM_GS_RNG_POS, TM_GS_N_NQ_FALLBACK,
+    TM_GS_LEAF, TM_GS_LEAF_END, TM_GS_K_EVAL, TM_GS_LEAF_SCORE
+};
+/* error bits in TM_GS_ERR */
+#define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
+#define TM_ERR_TRACE 2     /* trace longer than max_trace */
+#define TM_ERR_TABLE 4     /* transposition table full */
+
+/* agent numerics (which reference twin is reproduced bit for bit) */
+#define TM_KIND_VALUESIM 0     /* agents/ValueSim.py:76-94      : evaluate the leaf, fp64 carry             */
+#define TM_KIND_VALUESIM_LP 1  /* agents/ValueSimLP.py:44-70    : evaluate the leaf's unique children, core.h:303-381 */
+#define TM_KIND_CPPAGENT_LP 2  /* agent.cpp:420-436,517-566     : float carry, end_obs[o], no gamma^2       */
+#define TM_KIND_CPPAGENT 3     /* agent.cpp:437-446,496-513     : float carry, single leaf                 */
+
+typedef struct tm_store {
+    /* sizes */
+    int32_t n_games;      /* games owned by this process (one wavefront each) */
+    int32_t max_nodes;    /* node / observation pool size per game (agents/agent.py:36, ValueSim.py:16) */
+    int32_t table_cap;    /* transposition table slots per game, power of two >= 2*max_nodes */
+    int32_t max_trace;    /* trace capacity per game */
+    int32_t eval_slots;   /* leaf-evaluation slots per game: 1 (ValueSim) or 7 (leaf-parallel) */
+    int32_t nq_size;      /* entries in nq_table */
+    /* environment (pyTetris ctor arguments, play.py:75) */
+    int32_t app, scoring, randomizer;
+    /* search */
+    int32_t low;          /* check_low threshold (core.h:65-77): 1 for ValueSim/LP, 5 for Vanilla */
+    int32_t kind;         /* TM_KIND_* */
+    int32_t min_visits_to_store; /* ValueSim.py:14 / ValueSimLP.py:11 */
+    int32_t online;       /* harvest replay tuples on GC (ValueSim.py:109-115) */
+    int32_t replay_cap;   /* capacity (tuples) of the replay buffer */
+    double gamma;
+    /* node store, per game contiguous */
+    uint32_t *node_rec;   /* [G][N][24] hdr, self_obs, self_score, child[7], child_obs[7], child_score[7] */
+    uint32_t *node_game;  /* [G][N][16] packed game */
+    uint32_t *obs_stat;   /* [G][N][4]  visit(i32), value(f32), variance(f32), end(u32) */
+    uint32_t *obs_key;    /* [G][N][12] packed observation */
+    uint64_t *node_tab;   /* [G][cap]   (hash>>32)<<32 | node index ; index 0 = empty */
+    uint64_t *obs_tab;    /* [G][cap] */
+    int32_t *free_node;   /* [G][N] free-index stacks (pop from the end, agents/agent.py:99) */
+    int32_t *free_obs;    /* [G][N] */
+    int32_t *gs;          /* [G][16] control blocks */
+    uint32_t *rng;        /* [G][32] glibc rand() state (31 words) per game (core.h:62,76) */
+    uint32_t *env_game;   /* [G][16] the real games */
+    int32_t *env_line_stats; /* [G][4] */
+    uint32_t *trace;      /* [G][max_trace][4] node, obs, score bits, 0 */
+    int32_t *leaf;        /* [G][32] unique children of the leaf: node[7], obs[7], score bits[7], end[7] */
+    int32_t *eval_obs;    /* [G*eval_slots] observation index inside the game's pool, 0 = unused slot */
+    float *eval_v;        /* [G*eval_slots] evaluator outputs */
+    float *eval_var;
+    const float *nq_table;/* [nq_size] (float)norm_quantile(n), special.h:26-33, built on the host with libm */
+    uint8_t *gc_mark;     /* [G][2][N/8 rounded to 16B] scratch bitmaps for GC */
+    int32_t *gc_queue;    /* [G][N] BFS queue scratch */
+    /* replay tuples harvested at GC (ValueSim.py:122-159): per game ring, gathered by the host side */
+    uint32_t *replay_obs; /* [G][replay_cap][12] */
+    float *replay_stat;   /* [G][replay_cap][4] value, variance, visit, 0 */
+    int32_t *replay_count;/* [G] */
+} tm_store;
+
+/* pools, free lists, tables, rng (seed 1), control blocks.  Everything else must be zero-filled by the caller. */
+int tm_pool_init(const tm_store *s, void *stream);
+/* host helper: fills host_table[n] = (float)norm_quantile((double)i) with this machine's libm */
+void tm_fill_norm_quantile(float *host_table, int n);
+
+/* environment (batched pyTetris) */
+int tm_env_init(const tm_store *s, const uint32_t *seeds, void *stream);                /* Tetris(...) */
+int tm_env_step(const tm_store *s, const int32_t *actions, void *stream);               /* game.play(a) */
+int tm_env_reset(const tm_store *s, const uint8_t *mask, void *stream);                 /* game.reset() where mask!=0 (NULL: where ended) */
+int tm_env_render(const tm_store *s, int8_t *out /* [G][200] */, void *stream);         /* game.getState() */
+int tm_env_info(const tm_store *s, int32_t *out /* [G][8]: end, score, lines, combo, ls[4] */, void *stream);
+
+/* tree agent */
+int tm_update_root(const tm_store *s, void *stream);                                    /* agent.update_root(game) */
+#define TM_SIM_BACKUP 1  /* finish the pending simulation: backup with eval_v/eval_var */
+#define TM_SIM_FRONT 2   /* start one: select, expand, post evaluation requests into eval_obs */
+int tm_sim_step(const tm_store *s, int flags, void *stream);
+int tm_eval_render(const tm_store *s, int8_t *out /* [G*eval_slots][200] */, void *stream);
+int tm_root_stats(const tm_store *s, float *stats /* [G][3][7] */, int32_t *action /* [G] */, void *stream);
+/* one game's tree in the reference's array layout (agents/agent.py:58-88), for inspection and tests */
+int tm_export_game(const tm_store *s, int game, int32_t *child /* [N][7] */, float *score, int32_t *n_to_o,
+                   int32_t *visit, float *value, float *variance, uint8_t *end_obs, void *stream);
+
+/* agents.cppmodule.core (core.cpp:20-26) in batched form: B independent trees in the reference's own
+ * array layout, tree b at offset b*n_nodes of every array.  rng: [B][32] as in tm_store. */
+int tm_core_select_trace_obs(int n_trees, int n_nodes, const int32_t *roots, const int32_t *child,
+                             const int32_t *visit, const float *value, const float *variance, const float *score,
+                             const int32_t *n_to_o, int low, uint32_t *rng, const float *nq_table, int nq_size,
+                             int32_t *trace /* [B][max_trace] */, int32_t *trace_len, int max_trace, void *stream);
+int tm_core_backup_trace_obs(int n_trees, int n_nodes, const int32_t *trace, const int32_t *trace_len, int max_trace,
+                             int32_t *visit, float *value, float *variance, const int32_t *n_to_o, const float *score,
+                             const double *_value, const double *_variance, double gamma, void *stream);
+int tm_core_backup_trace_obs_lp(int n_trees, int n_nodes, const int32_t *trace, const int32_t *trace_len,
+                                int max_trace, int32_t *visit, float *value, float *variance, const int32_t *n_to_o,
+                                const float *score, const uint8_t *end, const int32_t *_child /* [B][7] */,
+                                const int32_t *_obs, const int32_t *k, const float *_value, const float *_variance,
+                                double gamma, void *stream);
+int tm_core_get_unique_child_obs(int n_trees, int n_nodes, const int32_t *index, const int32_t *child,
+                                 const float *score, const int32_t *n_to_o, int32_t *c_nodes /* [B][7] */,
+                                 int32_t *c_obs, int32_t *count, void *stream);
+int tm_core_get_all_childs(int n_trees, int n_nodes, const int32_t *roots, const int32_t *child,
+                           uint8_t *mark /* [B][n_nodes] */, int32_t *queue /* [B][n_nodes] scratch */, void *stream);
+
+/* value network forward (model/model_vv.py:13-52): states int8 [B][200] -> v[B], var[B]; params as in
+ * oracle/valuenet_oracle.c (PyTorch state_dict layouts).  scratch: [B][TM_VALUENET_SCRATCH] floats. */
+int tm_valuenet_forward(const float *params, const int8_t *states, int n, float *v, float *var, float *scratch,
+                        void *stream);
+
+const char *tm_version(void);
+/* sizeof(tm_store) and a few offsets, so a host mirror of the struct can be checked without a GPU */
+int tm_store_layout(int *out, int n);
+#ifdef __cplusplus
+}
+#endif
+#endif

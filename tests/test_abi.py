@@ -1,0 +1,58 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/tetris_mcts_hip.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    from tetris_mcts_amd import _lib
+    return _lib
+
+
+def test_every_declared_symbol_is_exported():
+    L = _lib()
+    lib = L.lib()
+    hdr = open(os.path.join(ROOT, "include", "tetris_mcts_hip.h")).read()
+    declared = set(re.findall(r"\b(tm_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(L.SYMBOLS) <= declared
+    assert lib.tm_version().startswith(b"tetris_mcts_hip")
+
+
+def test_store_layout_matches_ctypes_mirror():
+    L = _lib()
+    out = (C.c_int * 8)()
+    n = L.lib().tm_store_layout(out, 8)
+    T = L.TmStore
+    assert list(out)[:n] == [C.sizeof(T), T.gamma.offset, T.node_rec.offset, T.nq_table.offset, T.replay_count.offset]
+
+
+def test_norm_quantile_table_is_the_reference_formula(oracle):
+    L = _lib()
+    t = np.zeros(4096, np.float32)
+    with np.errstate(all="ignore"):
+        L.lib().tm_fill_norm_quantile(t.ctypes.data_as(C.c_void_p), len(t))
+    assert np.isnan(t[1]) and t[2] == 0.0
+    for n in (3, 7, 100, 4095):
+        assert t[n] == np.float32(oracle.lib().orc_norm_quantile(float(n)))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    L = _lib()
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libtetris_mcts_hip.so")
+    try:
+        L.lib()
+    except RuntimeError as e:
+        assert "no CPU path" in str(e)
+    else:
+        raise AssertionError("expected a loud failure")

@@ -1,0 +1,100 @@
+"""Batched agents.cppmodule.core drop-ins (core_api.hip) vs the reference's own outputs (ref_uct.npz)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from make_golden import random_dag  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_core_api_matches_reference_golden(golden_dir):
+    import torch
+    from tetris_mcts_amd import _lib
+    from tetris_mcts_amd.store import norm_quantile_table, _p, _stream
+    L = _lib.lib()
+    gold = np.load(os.path.join(golden_dir, "ref_uct.npz"))
+    rng = np.random.default_rng(20260925)
+    dev = torch.device("cuda")
+    nq = norm_quantile_table(1 << 16, dev)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    # The golden generator interleaves rng draws with results (k depends on the trace), so replay case by case
+    rng = np.random.default_rng(20260925)
+    for ci in range(24):
+        n_nodes, n_obs = 400, int(rng.integers(60, 300))
+        child, n_to_o, score, visit, value, variance = random_dag(rng, n_nodes, n_obs, low_visits=(ci % 2 == 0))
+        if ci == 3:
+            child[1] = 0
+            child[1][2] = 5
+            visit[n_to_o[5]] = 1
+        low = [1, 5][ci % 3 == 2]
+        N = n_nodes
+        padn = lambda a: np.concatenate([a, np.zeros(N - len(a), a.dtype)])  # noqa: E731
+        t_child, t_n2o, t_score = d(child), d(n_to_o), d(score)
+        t_visit, t_value, t_var = d(padn(visit)), d(padn(value)), d(padn(variance))
+        st = np.zeros(32, np.uint32)
+        # glibc srand(1) state through the oracle
+        from oracle import binding as B
+        o = np.zeros(36, np.int32)
+        B.lib().orc_srand(B.ptr(o), 1)
+        st[:31] = o[:31].view(np.uint32)
+        st[31] = int(o[34]) | (int(o[35]) << 8)
+        t_rng = d(st.view(np.int32))
+        name = "c%d" % ci
+        tcat, tlen, uniq = gold[name + "_tracecat"], gold[name + "_tracelen"], gold[name + "_uniq"]
+        off = 0
+        trace = torch.zeros(512, dtype=torch.int32, device=dev)
+        tl = torch.zeros(1, dtype=torch.int32, device=dev)
+        for rep in range(12):
+            root = int(rng.integers(1, 60))
+            t_root = d(np.array([root], np.int32))
+            _lib.check(L.tm_core_select_trace_obs(1, N, _p(t_root), _p(t_child), _p(t_visit), _p(t_value), _p(t_var),
+                                                  _p(t_score), _p(t_n2o), low, _p(t_rng), _p(nq), nq.numel(), _p(trace),
+                                                  _p(tl), 512, _stream()), "select")
+            n = int(tl.item())
+            assert n == tlen[rep], (ci, rep, n, tlen[rep])
+            assert np.array_equal(trace[:n].cpu().numpy(), tcat[off:off + n]), (ci, rep)
+            off += n
+            cn = torch.zeros(7, dtype=torch.int32, device=dev)
+            co = torch.zeros(7, dtype=torch.int32, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(L.tm_core_get_unique_child_obs(1, N, _p(t_root), _p(t_child), _p(t_score), _p(t_n2o), _p(cn),
+                                                      _p(co), _p(cnt), _stream()), "unique")
+            k = int(cnt.item())
+            u = uniq[rep]
+            assert u[15] == k and np.array_equal(u[1:1 + k], cn[:k].cpu().numpy()) and np.array_equal(u[8:8 + k], co[:k].cpu().numpy())
+            mode = rep % 3
+            if mode == 0:
+                v0, r0 = float(rng.random() * 90), float(rng.random() * 500)
+                _lib.check(L.tm_core_backup_trace_obs(1, N, _p(trace), _p(tl), 512, _p(t_visit), _p(t_value), _p(t_var),
+                                                      _p(t_n2o), _p(t_score), _p(d(np.array([v0]))), _p(d(np.array([r0]))),
+                                                      C.c_double(0.999), _stream()), "backup")
+            else:
+                leaf = d(np.array([int(trace[n - 1].item())], np.int32))
+                _lib.check(L.tm_core_get_unique_child_obs(1, N, _p(leaf), _p(t_child), _p(t_score), _p(t_n2o), _p(cn),
+                                                          _p(co), _p(cnt), _stream()), "unique")
+                k = int(cnt.item())
+                end = np.zeros(N, np.uint8)
+                if mode == 2 and k:
+                    end[int(cn[0].item())] = 1
+                _v = np.zeros(7, np.float32)
+                _r = np.zeros(7, np.float32)
+                _v[:k] = (rng.random(k) * 60).astype(np.float32)
+                _r[:k] = (rng.random(k) * 400).astype(np.float32)
+                _lib.check(L.tm_core_backup_trace_obs_lp(1, N, _p(trace), _p(tl), 512, _p(t_visit), _p(t_value), _p(t_var),
+                                                         _p(t_n2o), _p(t_score), _p(d(end)), _p(cn), _p(co), _p(cnt),
+                                                         _p(d(_v)), _p(d(_r)), C.c_double(0.999), _stream()), "backup_lp")
+        root = int(rng.integers(1, 60))
+        mark = torch.zeros(N, dtype=torch.uint8, device=dev)
+        queue = torch.zeros(N, dtype=torch.int32, device=dev)
+        _lib.check(L.tm_core_get_all_childs(1, N, _p(d(np.array([root], np.int32))), _p(t_child), _p(mark), _p(queue),
+                                            _stream()), "all_childs")
+        assert np.array_equal(np.nonzero(mark.cpu().numpy())[0].astype(np.int32), gold[name + "_reach"])
+        no = len(visit)
+        assert t_visit.cpu().numpy()[:no].tobytes() == gold[name + "_visit1"].tobytes(), ci
+        assert t_value.cpu().numpy()[:no].tobytes() == gold[name + "_value1"].tobytes(), ci
+        assert t_var.cpu().numpy()[:no].tobytes() == gold[name + "_variance1"].tobytes(), ci

@@ -1,0 +1,153 @@
+"""The HIP tree engine (tree.hip) vs the oracle agents, bit for bit: actions, scores, root statistics, whole
+tree arrays, across pool-exhaustion GCs and episode resets; and vs the reference's own golden runs."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gpu_helpers import hash_eval_torch
+
+pytestmark = pytest.mark.gpu
+KIND = {"ValueSim": 0, "ValueSimLP": 1}
+
+
+def _make(name, G, sims, max_nodes, seed, evaluator=None, model=None, **kw):
+    from tetris_mcts_amd import agents
+    from tetris_mcts_amd.pyTetris import Tetris
+    env_args = kw.pop("env_args", ((20, 10), 1, 0, 0))
+    game = Tetris(*env_args, seed=seed, n_games=G)
+    agent = getattr(agents, name)(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=max_nodes,
+                                  evaluator=evaluator, model=model, online=kw.pop("online", False), **kw)
+    agent.update_root(game)
+    return game, agent
+
+
+def _compare_run(oracle, name, G, sims, max_nodes, seed, moves, evaluator, params=None, model=None, env_args=None,
+                 check_tree_every=0):
+    env_args = env_args or ((20, 10), 1, 0, 0)
+    game, agent = _make(name, G, sims, max_nodes, seed, evaluator=hash_eval_torch if evaluator == "hash" else None,
+                        model=model, env_args=env_args)
+    og = [oracle.Game(env_args[1], env_args[2], env_args[3], seed + g) for g in range(G)]
+    oa = [oracle.Agent(KIND[name], max_nodes=max_nodes, app=env_args[1], scoring=env_args[2], randomizer=env_args[3],
+                       evaluator=evaluator, params=params) for _ in range(G)]
+    for g in range(G):
+        oa[g].update_root(og[g])
+    for m in range(moves):
+        act = np.atleast_1d(agent.play())
+        stats = agent.get_stats().reshape(G, 3, 7)
+        for g in range(G):
+            a = oa[g].play(sims)
+            assert oa[g].error == 0
+            assert a == act[g], (name, "move", m, "game", g, a, act[g], oa[g].stats(), stats[g])
+            assert oa[g].stats().tobytes() == stats[g].tobytes(), (name, "stats", m, g, oa[g].stats(), stats[g])
+            og[g].play(a)
+            oa[g].update_root(og[g])
+        game.play(act)
+        agent.update_root(game)
+        assert [o.score for o in og] == list(np.atleast_1d(game.score))
+        if check_tree_every and (m + 1) % check_tree_every == 0:
+            for g in (0, G - 1):
+                dev = agent.store.export_game(g)
+                ref = oa[g].arrays()
+                mark = np.zeros(max_nodes, np.uint8)
+                oracle.lib().orc_get_all_childs(oa[g].root, oracle.ptr(ref["child"]), max_nodes, oracle.ptr(mark))
+                occ = np.nonzero(mark)[0]
+                assert agent.store.t["gs"][g, 0].item() == oa[g].root
+                for k in ("child", "score", "n_to_o"):
+                    assert np.array_equal(dev[k][occ], ref[k][occ]), (k, m, g)
+                oo = np.unique(ref["n_to_o"][occ])
+                for k in ("visit", "value", "variance", "end_obs"):
+                    assert dev[k][oo].tobytes() == ref[k][oo].tobytes(), (k, m, g)
+        ended = np.atleast_1d(game.end)
+        if ended.any():
+            game.reset("ended")
+            for g in np.nonzero(ended)[0]:
+                og[g].reset()
+            agent.update_root(game)
+            for g in np.nonzero(ended)[0]:
+                oa[g].update_root(og[g])
+    gcs = sum(o.n_gc for o in oa)
+    assert agent.store.counter("N_GC") == gcs
+    assert agent.store.counter("N_EXPAND") == sum(o.n_expand for o in oa)
+    return gcs
+
+
+def test_valuesim_hash_eval_with_gc(oracle):
+    gcs = _compare_run(oracle, "ValueSim", G=6, sims=40, max_nodes=8000, seed=11, moves=150, evaluator="hash",
+                       check_tree_every=25)
+    assert gcs >= 1
+
+
+def test_valuesimlp_hash_eval_with_gc(oracle):
+    gcs = _compare_run(oracle, "ValueSimLP", G=6, sims=30, max_nodes=8000, seed=12, moves=150, evaluator="hash",
+                       check_tree_every=25)
+    assert gcs >= 1
+
+
+def test_valuesim_app2_uniform_randomizer(oracle):
+    _compare_run(oracle, "ValueSim", G=5, sims=30, max_nodes=20000, seed=5, moves=60, evaluator="hash",
+                 env_args=((20, 10), 2, 1, 1))
+
+
+def test_valuesimlp_app3(oracle):
+    _compare_run(oracle, "ValueSimLP", G=5, sims=25, max_nodes=20000, seed=6, moves=50, evaluator="hash",
+                 env_args=((20, 10), 3, 0, 0))
+
+
+@pytest.mark.parametrize("name,sims,moves", [("ValueSim", 25, 12), ("ValueSimLP", 10, 8)])
+def test_value_net_in_the_loop(oracle, golden_dir, name, sims, moves):
+    from tetris_mcts_amd.model import Model_VV
+    params = np.load(os.path.join(golden_dir, "ref_valuenet.npz"))["params"]
+    model = Model_VV(backend="hip")
+    model.set_flat_params(params)
+    _compare_run(oracle, name, G=4, sims=sims, max_nodes=100000, seed=13, moves=moves, evaluator="valuenet",
+                 params=params, model=model)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_reference_golden_runs(golden_dir, idx):
+    """tests/golden/ref_agents.json: the reference's own Python agents (make_golden.py)."""
+    from tetris_mcts_amd.model import Model_VV
+    with open(os.path.join(golden_dir, "ref_agents.json")) as f:
+        r = json.load(f)[idx]
+    model = None
+    if r["evaluator"] == "valuenet":
+        model = Model_VV(backend="hip")
+        model.set_flat_params(np.load(os.path.join(golden_dir, "ref_valuenet.npz"))["params"])
+    game, agent = _make(r["name"], 1, r["sims"], r["max_nodes"], r["seed"],
+                        evaluator=hash_eval_torch if r["evaluator"] == "hash" else None, model=model)
+    for i, (act, score, lines, stats_hex) in enumerate(r["moves"]):
+        got = agent.play()
+        assert got == act, (i, got, act)
+        assert agent.get_stats().astype("<f4").tobytes().hex() == stats_hex, i
+        game.play(got)
+        agent.update_root(game)
+        assert (game.score, game.line_clears) == (score, lines), i
+        if game.end:
+            game.reset()
+            agent.update_root(game)
+
+
+def test_full_size_batch_properties():
+    """4096 games x 500 sims (BASELINE config 2 sizes, hash evaluator): size-independent invariants."""
+    import torch
+    G, sims = 4096, 500
+    game, agent = _make("ValueSim", G, sims, 12000, 20260925, evaluator=hash_eval_torch)
+    agent.play()
+    st = agent.store
+    gs = st.t["gs"].cpu().numpy()
+    assert (gs[:, 6] == 0).all()                      # no error flags
+    assert (gs[:, 8] == sims).all()                   # every game ran every simulation
+    stats = agent.get_stats()
+    # each simulation passes through the root exactly once: root observation visits == sims
+    root = gs[:, 0]
+    rec = st.t["node_rec"][torch.arange(G, device="cuda"), torch.as_tensor(root, device="cuda").long()]
+    root_obs = rec[:, 1].long()
+    visits = st.t["obs_stat"][torch.arange(G, device="cuda"), root_obs, 0].cpu().numpy()
+    assert (visits == sims).all()
+    # the unique children of the root absorb all but the first simulation
+    assert (stats[:, 0].sum(axis=1) >= sims - 1).all()
+    # nodes allocated == pool size - free, and never more than 7 per expansion + the root
+    used = (12000 - 1) - gs[:, 2]
+    assert (used <= 7 * gs[:, 7] + 1).all() and (used >= gs[:, 7]).all()

@@ -1,0 +1,49 @@
+"""HIP value net vs the oracle (bit-exact) and vs the reference's own Net outputs (1e-4), plus the torch backend."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("pk,ok", [("params", "out"), ("params2", "out2")])
+def test_hip_valuenet(oracle, golden_dir, pk, ok):
+    import torch
+    from tetris_mcts_amd.model import Model_VV
+    z = np.load(os.path.join(golden_dir, "ref_valuenet.npz"))
+    m = Model_VV(backend="hip")
+    m.set_flat_params(z[pk])
+    states = torch.from_numpy(z["states"].reshape(-1, 200)).cuda()
+    # ragged batch sizes, including 1 and a non multiple of any tile
+    for B in (64, 1, 7, 33):
+        v, var = m.inference_device(states[:B].contiguous())
+        v, var = v.cpu().numpy(), var.cpu().numpy()
+        ov, ovar = np.zeros(B, np.float32), np.zeros(B, np.float32)
+        p = np.ascontiguousarray(z[pk])
+        s = np.ascontiguousarray(z["states"].reshape(-1, 200)[:B])
+        oracle.lib().orc_valuenet_forward(oracle.ptr(p), oracle.ptr(s), B, oracle.ptr(ov), oracle.ptr(ovar))
+        assert v.tobytes() == ov.tobytes() and var.tobytes() == ovar.tobytes(), (B, np.abs(v - ov).max(), np.abs(var - ovar).max())
+        ref = z[ok][:B]
+        scale = max(1.0, float(z[pk][478339]) / 1000.0)
+        assert np.abs(v - ref[:, 0]).max() <= TOL * max(1.0, float(z[pk][478338]) / 100.0)
+        assert np.abs(var - ref[:, 1]).max() <= TOL * scale
+    # batch invariance: a state's output does not depend on its neighbours
+    big = states.repeat(40, 1)[torch.randperm(64 * 40, device="cuda")]
+    v1, r1 = m.inference_device(big.contiguous())
+    v2, r2 = m.inference_device(big[:5].contiguous())
+    assert torch.equal(v1[:5], v2) and torch.equal(r1[:5], r2)
+
+
+def test_torch_backend_within_tolerance(golden_dir):
+    import torch
+    from tetris_mcts_amd.model import Model_VV
+    z = np.load(os.path.join(golden_dir, "ref_valuenet.npz"))
+    m = Model_VV(backend="torch")
+    m.set_flat_params(z["params"])
+    v, var = m.inference_device(torch.from_numpy(z["states"].reshape(-1, 200)).cuda())
+    assert np.abs(v.cpu().numpy() - z["out"][:, 0]).max() <= TOL
+    assert np.abs(var.cpu().numpy() - z["out"][:, 1]).max() <= TOL
+    out = m.inference(z["states"][:3, None].astype(np.float32))  # reference signature
+    assert out[0].shape == (3, 1) and out[1].shape == (3, 1)

@@ -1,0 +1,3 @@
+from .agent import Agent, TreeAgent  # noqa: F401
+from .ValueSim import ValueSim  # noqa: F401
+from .ValueSimLP import ValueSimLP  # noqa: F401

@@ -1,0 +1,137 @@
+"""Batched mirror of the reference's `Agent` / `TreeAgent` (agents/agent.py:10-307).
+
+Same surface — play(), get_action(), get_prob(), get_stats(), get_value_and_variance(), update_root(game),
+close() — over `n_games` concurrent games whose trees live on the GPU (store.TreeStore).  With n_games == 1
+return values have the reference's scalar shapes, so play.py drives it unchanged.
+"""
+import numpy as np
+import torch
+
+from .. import store as st
+
+
+class Agent:
+    def __init__(self, n_actions=7, benchmark=False, **kwargs):
+        self.episode = 0
+        self.n_actions = n_actions
+        self.benchmark = benchmark
+
+    def play(self):
+        raise NotImplementedError('update_root not implemented')
+
+    def get_action(self):
+        raise NotImplementedError('get_action not implemented')
+
+    def get_prob(self):
+        raise NotImplementedError('get_action not implemented')
+
+    def update_root(self, game):
+        raise NotImplementedError('update_root not implemented')
+
+    def close(self):
+        raise NotImplementedError('close not implemented')
+
+
+class TreeAgent(Agent):
+    kind = st.KIND_VALUESIM
+    low = 1
+
+    def __init__(self, sims=100, max_nodes=500000, env=None, env_args=None, node_saver=None, projection=True,
+                 min_visits=30, n_games=None, gamma=0.999, online=False, min_visits_to_store=10, replay_cap=0,
+                 max_trace=1024, nq_size=1 << 20, use_graph=True, **kwargs):
+        super().__init__(**kwargs)
+        if not projection:
+            raise NotImplementedError("projection=False is broken in the reference itself (ValueSim.py:73-74)")
+        self.sims = sims
+        self.max_nodes = max_nodes
+        self.env, self.env_args = env, env_args or ((20, 10), 1, 0, 0)
+        self.min_visits = min_visits
+        self.node_saver = node_saver
+        self.projection = True
+        self.gamma = gamma
+        self.n_games = n_games
+        self._store_kwargs = dict(kind=self.kind, env_args=self.env_args, gamma=gamma, low=self.low, online=online,
+                                  min_visits_to_store=min_visits_to_store, replay_cap=replay_cap, max_trace=max_trace,
+                                  nq_size=nq_size)
+        self.store = None
+        self.use_graph = use_graph
+        self._graph = None
+        self.stats = None
+        if n_games is not None:
+            self._build(n_games)
+
+    def _build(self, n_games):
+        self.n_games = int(n_games)
+        self.store = st.TreeStore(self.n_games, self.max_nodes, **self._store_kwargs)
+
+    # ---- evaluation hook (the `evaluator` callable of MCTSAgent, agent.cpp:396-405) ----
+    def evaluate(self, states, v_out, var_out):
+        raise NotImplementedError('evaluate not implemented for this agent.')
+
+    def _sim_body(self):
+        s = self.store
+        s.sim_step(st.SIM_BACKUP | st.SIM_FRONT)
+        states = s.render_eval()
+        self.evaluate(states, s.t["eval_v"], s.t["eval_var"])
+
+    def mcts(self, sims):
+        s = self.store
+        if self.use_graph and self._graph is None:
+            # warm up once eagerly (lazy initialisation inside torch / MIOpen must not be captured)
+            done = 0
+            if sims > 0:
+                self._sim_body()
+                done = 1
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._sim_body()
+            self._graph = g
+            for _ in range(sims - done):
+                g.replay()
+        elif self.use_graph:
+            for _ in range(sims):
+                self._graph.replay()
+        else:
+            for _ in range(sims):
+                self._sim_body()
+        s.sim_step(st.SIM_BACKUP)
+
+    def play(self):
+        self.mcts(self.sims)
+        return self.get_action()
+
+    def compute_stats(self):
+        stats, action = self.store.root_stats()
+        return stats, action
+
+    def get_action(self):
+        stats, action = self.compute_stats()
+        self._stats_dev, self._action_dev = stats, action
+        self.stats = None
+        err = self.store.errors()
+        a = action.cpu().numpy()
+        if bool((err != 0).any().item()):
+            raise RuntimeError("tree engine error flags: %s" % sorted(set(err.cpu().numpy().tolist())))
+        return int(a[0]) if self.n_games == 1 else a
+
+    def get_stats(self):
+        if self.stats is None:
+            self.stats = self._stats_dev.cpu().numpy()
+        return np.copy(self.stats[0]) if self.n_games == 1 else np.copy(self.stats)
+
+    def get_prob(self):
+        s = self.get_stats().reshape(-1, 3, 7)
+        p = s[:, 0] / s[:, 0].sum(axis=1, keepdims=True)
+        return p[0] if self.n_games == 1 else p
+
+    def update_root(self, game):
+        if self.store is None:
+            self._build(getattr(game, "n_games", 1))
+        self.store.set_root_games(game.games)
+        self.store.update_root()
+        ended = np.atleast_1d(game.end)
+        self.episode += int(ended.sum())
+
+    def close(self):
+        pass

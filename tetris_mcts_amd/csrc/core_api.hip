@@ -1,0 +1,227 @@
+// agents.cppmodule.core (agents/cppmodule/core.cpp:20-26) in batched form: B independent trees stored in the
+// reference's own array layout (agents/agent.py:58-88), tree b at offset b*n_nodes of every array.
+// One lane per tree: this is the compatibility surface (a drop-in for callers that own their numpy-style
+// arrays); the performance path is the fused one-wave-per-game engine in tree.hip.
+//   select_trace_obs core.h:167-224 | backup_trace_obs core.h:226-260 | backup_trace_obs_LP core.h:303-381
+//   get_unique_child_obs core.h:111-144 | get_all_childs core.h:32-50
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../../include/tetris_mcts_hip.h"
+
+namespace tmcts_core {
+
+__device__ inline float nq(const float* table, int size, int n) {
+    if (n >= 0 && n < size) return table[n];
+    double t = (double)n, alpha = 1 - 1 / t;
+    return (float)(10 * log(1 - log(-log(alpha) / log(2.0)) / log(22.0)) / log(41.0));
+}
+
+// rng: 31 state words + word 31 = f | b<<8  (glibc TYPE_3)
+__device__ inline uint32_t rand_next(uint32_t* r) {
+    int f = r[31] & 0xFF, b = (r[31] >> 8) & 0xFF;
+    uint32_t val = r[f] + r[b];
+    r[f] = val;
+    f += 1;
+    if (f >= 31) { f = 0; b += 1; }
+    else { b += 1; if (b >= 31) b = 0; }
+    r[31] = (uint32_t)(f | (b << 8));
+    return val >> 1;
+}
+
+__device__ inline int unique_child_obs(int index, const int32_t* child, const float* score, const int32_t* n_to_o,
+                                       int32_t* cn, int32_t* co) {
+    int n = 0;
+    for (int i = 0; i < 7; ++i) {
+        int c = child[(size_t)index * 7 + i];
+        if (c == 0) continue;
+        int o = n_to_o[c];
+        int found = -1;
+        for (int j = 0; j < n; ++j)
+            if (co[j] == o) { found = j; break; }
+        if (found < 0) { cn[n] = c; co[n] = o; n += 1; }
+        else if (score[c] > score[cn[found]]) cn[found] = c;
+    }
+    return n;
+}
+
+__global__ void k_select(int B, int N, const int32_t* roots, const int32_t* child, const int32_t* visit,
+                         const float* value, const float* variance, const float* score, const int32_t* n_to_o, int low,
+                         uint32_t* rng, const float* nq_table, int nq_size, int32_t* trace, int32_t* trace_len,
+                         int max_trace) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    size_t off = (size_t)b * N;
+    child += off * 7; visit += off; value += off; variance += off; score += off; n_to_o += off;
+    uint32_t* r = rng + (size_t)b * 32;
+    int32_t* tr = trace + (size_t)b * max_trace;
+    int index = roots[b], len = 0;
+    int32_t cn[7], co[7];
+    for (;;) {
+        if (len >= max_trace) { len = -1; break; }
+        tr[len++] = index;
+        int n = unique_child_obs(index, child, score, n_to_o, cn, co);
+        if (n == 0) break;
+        int32_t lows[7];
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+            if (visit[co[i]] < low) lows[m++] = co[i];
+        if (m > 0) {
+            int o = lows[rand_next(r) % (uint32_t)m];
+            for (int i = 0; i < n; ++i)
+                if (co[i] == o) { index = cn[i]; break; }
+        } else {
+            int total = 0;
+            for (int i = 0; i < n; ++i) total += visit[co[i]];
+            float coeff = nq(nq_table, nq_size, total);
+            int best = 0;
+            float max_q = 0;
+            for (int i = 0; i < n; ++i) {
+                float t1 = value[co[i]] + score[cn[i]];
+                float val = t1 - score[index];
+                float ratio = variance[co[i]] / (float)visit[co[i]];
+                float root = sqrtf(ratio);
+                float prod = coeff * root;
+                float q = val + prod;
+                if (i == 0) max_q = q;
+                else if (q > max_q) { max_q = q; best = i; }
+            }
+            index = cn[best];
+        }
+    }
+    trace_len[b] = len;
+}
+
+__device__ inline void backup_one(const int32_t* tr, int len, int32_t* visit, float* value, float* variance,
+                                  const int32_t* n_to_o, const float* score, double _value, double _variance,
+                                  double gamma) {
+    for (int i = len - 1; i >= 0; --i) {
+        int idx = tr[i];
+        _value = _value - (double)score[idx];
+        int o = n_to_o[idx];
+        if (visit[o] == 0) {
+            value[o] = (float)_value;
+            variance[o] = (float)_variance;
+        } else {
+            double delta = _value - (double)value[o];
+            value[o] = (float)((double)value[o] + delta / (double)(visit[o] + 1));
+            double delta2 = _value - (double)value[o];
+            double prod = delta * delta2;
+            variance[o] = (float)((double)variance[o] + (prod - (double)variance[o]) / (double)(visit[o] + 1));
+        }
+        visit[o] += 1;
+        double t = gamma * _value;
+        _value = t + (double)score[idx];
+    }
+}
+
+__global__ void k_backup(int B, int N, const int32_t* trace, const int32_t* trace_len, int max_trace, int32_t* visit,
+                         float* value, float* variance, const int32_t* n_to_o, const float* score, const double* _value,
+                         const double* _variance, double gamma) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    size_t off = (size_t)b * N;
+    backup_one(trace + (size_t)b * max_trace, trace_len[b], visit + off, value + off, variance + off, n_to_o + off,
+               score + off, _value[b], _variance[b], gamma);
+}
+
+__global__ void k_backup_lp(int B, int N, const int32_t* trace, const int32_t* trace_len, int max_trace, int32_t* visit,
+                            float* value, float* variance, const int32_t* n_to_o, const float* score, const uint8_t* end,
+                            const int32_t* _child, const int32_t* _obs, const int32_t* kk, const float* _value,
+                            const float* _variance, double gamma) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    size_t off = (size_t)b * N;
+    visit += off; value += off; variance += off; n_to_o += off; score += off; end += off;
+    const int32_t* tr = trace + (size_t)b * max_trace;
+    int len = trace_len[b], k = kk[b];
+    if (k > 0) {
+        double v_tmp = 0, var_tmp = 0;
+        for (int i = 0; i < k; ++i) {
+            int c = _child[b * 7 + i], o = _obs[b * 7 + i];
+            if (visit[o] == 0) {
+                visit[o] += 1;
+                if (end[c]) { value[o] = 0; variance[o] = 0; }
+                else { value[o] = _value[b * 7 + i]; variance[o] = _variance[b * 7 + i]; }
+            }
+            double gv = gamma * (double)value[o];
+            v_tmp = v_tmp + ((double)score[c] + gv);
+            var_tmp = var_tmp + (double)variance[o];
+        }
+        v_tmp = v_tmp / (double)k;
+        var_tmp = var_tmp * (gamma * gamma / (double)k);
+        backup_one(tr, len, visit, value, variance, n_to_o, score, v_tmp, var_tmp, gamma);
+    } else {
+        backup_one(tr, len, visit, value, variance, n_to_o, score, (double)score[tr[len - 1]], 0, gamma);
+    }
+}
+
+__global__ void k_unique(int B, int N, const int32_t* index, const int32_t* child, const float* score,
+                         const int32_t* n_to_o, int32_t* c_nodes, int32_t* c_obs, int32_t* count) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    size_t off = (size_t)b * N;
+    int32_t cn[7] = {0, 0, 0, 0, 0, 0, 0}, co[7] = {0, 0, 0, 0, 0, 0, 0};
+    int n = unique_child_obs(index[b], child + off * 7, score + off, n_to_o + off, cn, co);
+    for (int i = 0; i < 7; ++i) { c_nodes[b * 7 + i] = cn[i]; c_obs[b * 7 + i] = co[i]; }
+    count[b] = n;
+}
+
+__global__ void k_all_childs(int B, int N, const int32_t* roots, const int32_t* child, uint8_t* mark, int32_t* queue) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    size_t off = (size_t)b * N;
+    child += off * 7; mark += off; queue += off;
+    for (int i = 0; i < N; ++i) mark[i] = 0;
+    int head = 0, tail = 0;
+    queue[tail++] = roots[b];
+    mark[roots[b]] = 1;
+    while (head < tail) {
+        int n = queue[head++];
+        for (int a = 0; a < 7; ++a) {
+            int c = child[(size_t)n * 7 + a];
+            if (!mark[c]) { mark[c] = 1; queue[tail++] = c; }
+        }
+    }
+}
+
+}  // namespace tmcts_core
+
+using namespace tmcts_core;
+#define GRID(B) dim3(((B) + 63) / 64), dim3(64), 0, (hipStream_t)stream
+
+extern "C" {
+int tm_core_select_trace_obs(int B, int N, const int32_t* roots, const int32_t* child, const int32_t* visit,
+                             const float* value, const float* variance, const float* score, const int32_t* n_to_o,
+                             int low, uint32_t* rng, const float* nq_table, int nq_size, int32_t* trace,
+                             int32_t* trace_len, int max_trace, void* stream) {
+    hipLaunchKernelGGL(k_select, GRID(B), B, N, roots, child, visit, value, variance, score, n_to_o, low, rng, nq_table,
+                       nq_size, trace, trace_len, max_trace);
+    return (int)hipGetLastError();
+}
+int tm_core_backup_trace_obs(int B, int N, const int32_t* trace, const int32_t* trace_len, int max_trace, int32_t* visit,
+                             float* value, float* variance, const int32_t* n_to_o, const float* score,
+                             const double* _value, const double* _variance, double gamma, void* stream) {
+    hipLaunchKernelGGL(k_backup, GRID(B), B, N, trace, trace_len, max_trace, visit, value, variance, n_to_o, score,
+                       _value, _variance, gamma);
+    return (int)hipGetLastError();
+}
+int tm_core_backup_trace_obs_lp(int B, int N, const int32_t* trace, const int32_t* trace_len, int max_trace,
+                                int32_t* visit, float* value, float* variance, const int32_t* n_to_o, const float* score,
+                                const uint8_t* end, const int32_t* _child, const int32_t* _obs, const int32_t* k,
+                                const float* _value, const float* _variance, double gamma, void* stream) {
+    hipLaunchKernelGGL(k_backup_lp, GRID(B), B, N, trace, trace_len, max_trace, visit, value, variance, n_to_o, score,
+                       end, _child, _obs, k, _value, _variance, gamma);
+    return (int)hipGetLastError();
+}
+int tm_core_get_unique_child_obs(int B, int N, const int32_t* index, const int32_t* child, const float* score,
+                                 const int32_t* n_to_o, int32_t* c_nodes, int32_t* c_obs, int32_t* count, void* stream) {
+    hipLaunchKernelGGL(k_unique, GRID(B), B, N, index, child, score, n_to_o, c_nodes, c_obs, count);
+    return (int)hipGetLastError();
+}
+int tm_core_get_all_childs(int B, int N, const int32_t* roots, const int32_t* child, uint8_t* mark, int32_t* queue,
+                           void* stream) {
+    hipLaunchKernelGGL(k_all_childs, GRID(B), B, N, roots, child, mark, queue);
+    return (int)hipGetLastError();
+}
+}

@@ -1,0 +1,1061 @@
+// Batched Tetris-MCTS tree engine for gfx950: one wavefront per game.
+//
+// Reference behaviour reproduced (bit for bit on integers and floats):
+//   new_node / expand      agents/agent.py:90-145 (agent.cpp:201-264)
+//   select_trace_obs       agents/cppmodule/core.h:167-224 (check_low 65-77, policy_clt 83-105,
+//                          get_unique_child_obs 111-144)
+//   backup_trace_obs       core.h:226-260 ; backup_trace_obs_LP core.h:303-381 ;
+//   MCTSAgent twins        agent.cpp:496-566
+//   compute_stats/get_action agents/agent.py:153-185
+// Layout and kernel design: DESIGN.md.  Node record (96 B) keeps, next to the child indices, each
+// child's observation index and score and the precomputed unique-child list, so a tree level costs two
+// dependent memory round trips (record, then the <=7 observation statistics) instead of three.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "engine.cuh"
+#include "../../include/tetris_mcts_hip.h"
+
+namespace tmcts {
+
+constexpr int WPB = 4;  // wavefronts (games) per workgroup
+
+struct WaveLds {
+    uint32_t slots[8][GAME_DW];  // 0..6 successor games, 7 the parent
+    uint32_t okeys[7][OBS_DW];
+    uint32_t rng[32];
+    uint32_t misc[64];
+};
+
+struct GP {  // base pointers of one game
+    uint32_t *rec, *game, *stat, *okey;
+    uint64_t *ntab, *otab;
+    int32_t *fnode, *fobs, *gs, *leaf, *eval_obs;
+    uint32_t* trace;
+    float *eval_v, *eval_var;
+};
+
+__device__ __forceinline__ GP game_ptrs(const tm_store& S, int g) {
+    GP P;
+    size_t n = (size_t)S.max_nodes, gg = (size_t)g;
+    P.rec = S.node_rec + gg * n * TM_REC_DW;
+    P.game = S.node_game + gg * n * TM_GAME_DW;
+    P.stat = S.obs_stat + gg * n * 4;
+    P.okey = S.obs_key + gg * n * TM_OBS_DW;
+    P.ntab = S.node_tab + gg * (size_t)S.table_cap;
+    P.otab = S.obs_tab + gg * (size_t)S.table_cap;
+    P.fnode = S.free_node + gg * n;
+    P.fobs = S.free_obs + gg * n;
+    P.gs = S.gs + gg * TM_GS_DW;
+    P.leaf = S.leaf + gg * TM_LEAF_DW;
+    P.eval_obs = S.eval_obs + gg * S.eval_slots;
+    P.eval_v = S.eval_v + gg * S.eval_slots;
+    P.eval_var = S.eval_var + gg * S.eval_slots;
+    P.trace = S.trace + gg * (size_t)S.max_trace * 4;
+    return P;
+}
+
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ uint32_t shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    uint32_t lo = shfl_u32((uint32_t)v, src), hi = shfl_u32((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    return __longlong_as_double((long long)shfl_u64((uint64_t)__double_as_longlong(v), src));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// glibc rand() (TYPE_3, r[i] = r[i-3] + r[i-31]; core.h:62,76 call the process-global generator, here
+// one stream per game, all lanes of the wave step it redundantly on the LDS copy)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_rand(WaveLds& L, int& pos) {
+    int f = pos & 0xFF, b = (pos >> 8) & 0xFF;
+    uint32_t val = L.rng[f] + L.rng[b];
+    wave_sync();
+    L.rng[f] = val;
+    wave_sync();
+    f += 1;
+    if (f >= 31) { f = 0; b += 1; }
+    else { b += 1; if (b >= 31) b = 0; }
+    pos = f | (b << 8);
+    return val >> 1;
+}
+
+__device__ inline void srand_state(uint32_t* r /* 32 words */, int& pos, uint32_t seed) {
+    if (seed == 0) seed = 1;
+    int32_t word = (int32_t)seed;
+    r[0] = (uint32_t)word;
+    for (int i = 1; i < 31; ++i) {
+        long long hi = word / 127773, lo = word % 127773;
+        long long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        word = (int32_t)w;
+        r[i] = (uint32_t)word;
+    }
+    r[31] = 0;
+    int f = 3, b = 0;
+    for (int i = 0; i < 310; ++i) {
+        r[f] = r[f] + r[b];
+        f += 1;
+        if (f >= 31) { f = 0; b += 1; }
+        else { b += 1; if (b >= 31) b = 0; }
+    }
+    pos = f | (b << 8);
+}
+
+// special.h:26-33, used only beyond the host-built table (counted in TM_GS_N_NQ_FALLBACK)
+__device__ inline float norm_quantile_dev(double t) {
+    double alpha = 1 - 1 / t;
+    return (float)(10 * log(1 - log(-log(alpha) / log(2.0)) / log(22.0)) / log(41.0));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// new_node for up to 7 candidate games held in L.slots[0..n) (agents/agent.py:90-130 applied in action
+// order).  Lane a (< n) owns candidate a.  Returns the node and observation index per lane.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool eq_lds(const uint32_t* a, const uint32_t* b, int ndw) {
+    uint32_t d = 0;
+    for (int i = 0; i < ndw; ++i) d |= a[i] ^ b[i];
+    return d == 0;
+}
+__device__ __forceinline__ bool eq_glb(const uint32_t* lds, const uint32_t* glb, int nq /* uint4 count */) {
+    const uint4* q = reinterpret_cast<const uint4*>(glb);
+    uint32_t d = 0;
+    for (int i = 0; i < nq; ++i) {
+        uint4 v = q[i];
+        d |= (v.x ^ lds[4 * i]) | (v.y ^ lds[4 * i + 1]) | (v.z ^ lds[4 * i + 2]) | (v.w ^ lds[4 * i + 3]);
+    }
+    return d == 0;
+}
+
+// Probe an open-addressing table (slot = tag<<32 | index, index 0 = empty).  Returns the index of
+// the entry whose stored record equals `key`, or 0 with `ins` = first empty slot.
+__device__ __forceinline__ int table_find(const uint64_t* tab, uint32_t mask, uint64_t h, const uint32_t* key,
+                                          const uint32_t* pool, int rec_dw, uint32_t& ins, bool& full) {
+    uint32_t tag = (uint32_t)(h >> 32);
+    uint32_t s = (uint32_t)h & mask;
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+        uint64_t e = tab[s];
+        uint32_t idx = (uint32_t)e;
+        if (idx == 0) { ins = s; return 0; }
+        if ((uint32_t)(e >> 32) == tag && eq_glb(key, pool + (size_t)idx * rec_dw, rec_dw / 4)) return (int)idx;
+        s = (s + 1) & mask;
+    }
+    full = true;
+    ins = 0;
+    return 0;
+}
+
+// Insert entries of the lanes in `need` one lane at a time (ascending lane = action order), skipping
+// slots claimed earlier in this call (another lane of this wave may have probed the same empty slot).
+__device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, uint64_t need, int n, int lane,
+                                                 uint64_t h, uint32_t ins, int idx, uint32_t* claimed) {
+    int ncl = 0;
+    for (int b = 0; b < n; ++b) {
+        if (!((need >> b) & 1ull)) continue;
+        if (lane == b) {
+            uint32_t s = ins;
+            for (;;) {
+                bool cl = false;
+                for (int j = 0; j < ncl; ++j) cl |= (claimed[j] == s);
+                if (!cl && (s == ins || (uint32_t)tab[s] == 0)) break;
+                s = (s + 1) & mask;
+            }
+            tab[s] = ((h >> 32) << 32) | (uint32_t)idx;
+            claimed[ncl] = s;
+        }
+        ncl += 1;
+        wave_sync();
+    }
+}
+
+__device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane);
+
+__device__ inline void wave_new_nodes(const tm_store& S, const GP& P, WaveLds& L, int g, int n, int lane,
+                                      int& r_idx, int& r_obs) {
+    const bool act = lane < n;
+    const uint32_t* my = L.slots[act ? lane : 0];
+    const uint32_t mask = (uint32_t)S.table_cap - 1u;
+    uint64_t h = hash_game(my);
+    // 1. candidates that are equal to an earlier candidate reuse its node (dict hit in the reference)
+    int dup = lane;
+    for (int b = 0; b < n; ++b) {
+        uint64_t hb = shfl_u64(h, b);
+        if (act && dup == lane && b < lane && hb == h && eq_lds(my, L.slots[b], GAME_DW)) dup = b;
+    }
+    const bool uniq = act && dup == lane;
+    // 2. transposition lookup by full state equality
+    int found = 0;
+    uint32_t ins = 0;
+    bool full = false;
+    if (uniq) found = table_find(P.ntab, mask, h, my, P.game, GAME_DW, ins, full);
+    bool isnew = uniq && !found && !full;
+    uint64_t need = __ballot(isnew);
+    int cnt = __popcll(need);
+    int nfree = P.gs[TM_GS_NFREE_NODE];
+    if (__any(full)) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_TABLE); }
+    if (cnt > nfree) {
+        // Pool exhausted: the reference reclaims unreachable nodes at exactly this pop
+        // (agents/agent.py:96-97).  Candidates before the exhausting one are inserted first, exactly as
+        // the sequential reference does, then the wave collects garbage and the rest is retried.
+        // Handled by the caller-visible slow path below.
+        r_idx = -1;
+        r_obs = nfree;  // tells the caller how many can still be taken
+        return;
+    }
+    int idx = found;
+    if (isnew) idx = P.fnode[nfree - 1 - __popcll(need & ((1ull << lane) - 1ull))];
+    if (lane == 0 && cnt) P.gs[TM_GS_NFREE_NODE] = nfree - cnt;
+    table_insert_seq(P.ntab, mask, need, n, lane, h, ins, idx, L.misc);
+    // 3. observations of the new nodes (agents/agent.py:112-128)
+    uint32_t* ok = L.okeys[act ? lane : 0];
+    uint64_t ho = 0;
+    if (isnew) { pack_obs(my, ok); ho = hash_obs(ok); }
+    wave_sync();
+    int odup = lane;
+    for (int b = 0; b < n; ++b) {
+        uint64_t hb = shfl_u64(ho, b);
+        bool bnew = (need >> b) & 1ull;
+        if (isnew && bnew && odup == lane && b < lane && hb == ho && eq_lds(ok, L.okeys[b], OBS_DW)) odup = b;
+    }
+    const bool ouniq = isnew && odup == lane;
+    int ofound = 0;
+    uint32_t oins = 0;
+    bool ofull = false;
+    if (ouniq) ofound = table_find(P.otab, mask, ho, ok, P.okey, OBS_DW, oins, ofull);
+    bool onew = ouniq && !ofound && !ofull;
+    uint64_t oneed = __ballot(onew);
+    int ocnt = __popcll(oneed);
+    int onfree = P.gs[TM_GS_NFREE_OBS];
+    int o = ofound;
+    if (onew) o = P.fobs[onfree - 1 - __popcll(oneed & ((1ull << lane) - 1ull))];
+    if (lane == 0 && ocnt) P.gs[TM_GS_NFREE_OBS] = onfree - ocnt;
+    table_insert_seq(P.otab, mask, oneed, n, lane, ho, oins, o, L.misc + 8);
+    if (onew) {
+        uint4* dst = reinterpret_cast<uint4*>(P.okey + (size_t)o * OBS_DW);
+        dst[0] = make_uint4(ok[0], ok[1], ok[2], ok[3]);
+        dst[1] = make_uint4(ok[4], ok[5], ok[6], ok[7]);
+        dst[2] = make_uint4(ok[8], ok[9], ok[10], ok[11]);
+        P.stat[(size_t)o * 4 + 3] = ok[11] & 0xFFu;  // obs_arrays['end'] (agents/agent.py:123)
+    }
+    {   // same observation as an earlier new candidate
+        int osrc = shfl_u32((uint32_t)o, odup);
+        if (isnew && odup != lane) o = osrc;
+    }
+    if (isnew) {
+        uint4* dst = reinterpret_cast<uint4*>(P.game + (size_t)idx * GAME_DW);
+        dst[0] = make_uint4(my[0], my[1], my[2], my[3]);
+        dst[1] = make_uint4(my[4], my[5], my[6], my[7]);
+        dst[2] = make_uint4(my[8], my[9], my[10], my[11]);
+        dst[3] = make_uint4(my[12], my[13], my[14], my[15]);
+        uint32_t* r = P.rec + (size_t)idx * TM_REC_DW;
+        r[0] = ((my[11] >> 8) & 1u) << 24;               // end flag of the node's game
+        r[1] = (uint32_t)o;                              // node_to_obs
+        r[2] = __float_as_uint((float)(int)my[14]);      // arrays['score'][idx] = game.score (float32)
+    }
+    if (uniq && found) o = (int)P.rec[(size_t)found * TM_REC_DW + 1];
+    {
+        int isrc = shfl_u32((uint32_t)idx, dup), osrc = shfl_u32((uint32_t)o, dup);
+        if (act && dup != lane) { idx = isrc; o = osrc; }
+    }
+    r_idx = idx;
+    r_obs = o;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// expand (agents/agent.py:136-145): 7 successors of `leaf`, written into the leaf's record together
+// with the unique-child list of get_unique_child_obs (core.h:111-144).
+// Per-lane outputs for lane a < 7: child node / obs / score bits.  Returns false on pool exhaustion.
+// ---------------------------------------------------------------------------------------------------
+__device__ inline bool wave_expand(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
+                                   uint32_t& hdr_out) {
+    if (lane < GAME_DW) L.slots[7][lane] = P.game[(size_t)leaf * GAME_DW + lane];
+    wave_sync();
+    for (int t = lane; t < 7 * GAME_DW; t += 64) L.slots[t >> 4][t & 15] = L.slots[7][t & 15];
+    wave_sync();
+    EngCfg cfg{S.app, S.scoring, S.randomizer};
+    if (lane < 7) {
+        Piece p;
+        load_fields(L.slots[lane], p);
+        play(reinterpret_cast<uint16_t*>(L.slots[lane]), p, cfg, lane, nullptr);
+        store_fields(L.slots[lane], p);
+    }
+    wave_sync();
+    int idx, o;
+    wave_new_nodes(S, P, L, g, 7, lane, idx, o);
+    if (idx < 0) {
+        // slow path: sequential new_node with a GC at the exhausting pop (rare: once per ~50 moves)
+        int out_idx = 0, out_o = 0;
+        for (int a = 0; a < 7; ++a) {
+            // move candidate a into slot 0 of a scratch view: reuse slot 7 (the parent copy is no longer needed)
+            if (lane < GAME_DW) L.slots[7][lane] = L.slots[a][lane];
+            wave_sync();
+            // run a 1-candidate new_node on slot 7 by temporarily swapping it with slot 0
+            uint32_t keep = 0;
+            if (lane < GAME_DW) { keep = L.slots[0][lane]; L.slots[0][lane] = L.slots[7][lane]; }
+            wave_sync();
+            int i1, o1;
+            wave_new_nodes(S, P, L, g, 1, lane, i1, o1);
+            if (i1 < 0) {
+                gc_wave(S, P, L, g, lane);
+                wave_new_nodes(S, P, L, g, 1, lane, i1, o1);
+                if (i1 < 0) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_POOL); i1 = 0; o1 = 0; }
+            }
+            i1 = (int)shfl_u32((uint32_t)i1, 0);
+            o1 = (int)shfl_u32((uint32_t)o1, 0);
+            if (lane < GAME_DW) L.slots[0][lane] = keep;
+            wave_sync();
+            if (lane == a) { out_idx = i1; out_o = o1; }
+            // the reference links child[idx][a] right after each new_node (agent.py:145), which is what
+            // makes earlier successors reachable for a later GC
+            if (lane == 0) {
+                uint32_t* r = P.rec + (size_t)leaf * TM_REC_DW;
+                r[3 + a] = (uint32_t)i1;
+                r[10 + a] = (uint32_t)o1;
+                r[17 + a] = __float_as_uint((float)(int)L.slots[a][14]);
+            }
+            wave_sync();
+        }
+        idx = out_idx;
+        o = out_o;
+    }
+    uint32_t sbits = __float_as_uint((float)(int)L.slots[lane < 7 ? lane : 0][14]);
+    if (lane < 7) {
+        uint32_t* r = P.rec + (size_t)leaf * TM_REC_DW;
+        r[3 + lane] = (uint32_t)idx;
+        r[10 + lane] = (uint32_t)o;
+        r[17 + lane] = sbits;
+        L.misc[16 + lane] = (uint32_t)idx;
+        L.misc[24 + lane] = (uint32_t)o;
+        L.misc[32 + lane] = sbits;
+    }
+    wave_sync();
+    // get_unique_child_obs (core.h:126-142), evaluated once here because its inputs never change
+    if (lane == 0) {
+        int nu = 0;
+        for (int a = 0; a < 7; ++a) {
+            uint32_t c = L.misc[16 + a];
+            if (c == 0) continue;
+            uint32_t ob = L.misc[24 + a];
+            int j = -1;
+            for (int t = 0; t < nu; ++t)
+                if (L.misc[48 + t] == ob) { j = t; break; }
+            if (j < 0) { L.misc[40 + nu] = (uint32_t)a; L.misc[48 + nu] = ob; nu += 1; }
+            else if (__uint_as_float(L.misc[32 + a]) > __uint_as_float(L.misc[32 + L.misc[40 + j]])) L.misc[40 + j] = (uint32_t)a;
+        }
+        uint32_t hdr = (uint32_t)nu | (1u << 25);
+        for (int t = 0; t < nu; ++t) hdr |= L.misc[40 + t] << (3 + 3 * t);
+        L.misc[56] = hdr;
+        P.rec[(size_t)leaf * TM_REC_DW] = hdr;
+    }
+    wave_sync();
+    hdr_out = L.misc[56];
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Welford update of one observation (core.h:248-257); fp64 arithmetic, fp32 storage, no contraction
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void welford_f64(uint32_t* st, double x, double var_in) {
+    uint4 s = *reinterpret_cast<uint4*>(st);
+    int visit = (int)s.x;
+    float value = __uint_as_float(s.y), variance = __uint_as_float(s.z);
+    if (visit == 0) {
+        value = (float)x;
+        variance = (float)var_in;
+    } else {
+        double delta = x - (double)value;
+        value = (float)((double)value + delta / (double)(visit + 1));
+        double delta2 = x - (double)value;
+        double prod = delta * delta2;
+        variance = (float)((double)variance + (prod - (double)variance) / (double)(visit + 1));
+    }
+    st[0] = (uint32_t)(visit + 1);
+    st[1] = __float_as_uint(value);
+    st[2] = __float_as_uint(variance);
+}
+// agent.cpp:496-513: the carried value is a float
+__device__ __forceinline__ void welford_f32carry(uint32_t* st, float x, float var_in) {
+    uint4 s = *reinterpret_cast<uint4*>(st);
+    int visit = (int)s.x;
+    float value = __uint_as_float(s.y), variance = __uint_as_float(s.z);
+    if (visit == 0) {
+        value = x;
+        variance = var_in;
+    } else {
+        double delta = (double)(x - value);
+        value = (float)((double)value + delta / (double)(visit + 1));
+        double delta2 = (double)(x - value);
+        double prod = delta * delta2;
+        variance = (float)((double)variance + (prod - (double)variance) / (double)(visit + 1));
+    }
+    st[0] = (uint32_t)(visit + 1);
+    st[1] = __float_as_uint(value);
+    st[2] = __float_as_uint(variance);
+}
+
+// backup of the stored trace.  Entries are handled 64 at a time from the leaf end; the carried value
+// is a pure function of the scores, so every lane replays the recurrence and keeps its own entry's
+// value; the observation updates are independent unless an observation repeats in the trace, which
+// ENGINE_SPEC.md rules out for app == 1 (checked, with a sequential fallback, when app > 1).
+__device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lane, int len, double v0, double var0,
+                                         bool float_carry) {
+    const double gamma = S.gamma;
+    double V = v0;
+    float Vf = (float)v0;
+    const float varf = (float)var0;
+    for (int base = 0; base < len; base += 64) {
+        int cnt = min(64, len - base);
+        int i = len - 1 - base - lane;
+        uint4 e = make_uint4(0, 0, 0, 0);
+        if (lane < cnt) e = reinterpret_cast<const uint4*>(P.trace)[i];
+        float sc = __uint_as_float(e.z);
+        double x = 0;
+        float xf = 0;
+        for (int j = 0; j < cnt; ++j) {
+            float sj = __uint_as_float(shfl_u32(e.z, j));
+            if (float_carry) {
+                Vf = Vf - sj;
+                if (lane == j) xf = Vf;
+                double t = gamma * (double)Vf;
+                Vf = (float)(t + (double)sj);
+            } else {
+                V = V - (double)sj;
+                if (lane == j) x = V;
+                double t = gamma * V;
+                V = t + (double)sj;
+            }
+        }
+        (void)sc;
+        if (lane < cnt) {
+            uint32_t* st = P.stat + (size_t)e.y * 4;
+            if (float_carry) welford_f32carry(st, xf, varf);
+            else welford_f64(st, x, var0);
+        }
+    }
+}
+// strictly sequential form (one lane), used when an observation may repeat inside the trace
+__device__ inline void lane_backup_trace_seq(const tm_store& S, const GP& P, int len, double v0, double var0,
+                                             bool float_carry) {
+    const double gamma = S.gamma;
+    double V = v0;
+    float Vf = (float)v0;
+    for (int i = len - 1; i >= 0; --i) {
+        uint4 e = reinterpret_cast<const uint4*>(P.trace)[i];
+        float sj = __uint_as_float(e.z);
+        uint32_t* st = P.stat + (size_t)e.y * 4;
+        if (float_carry) {
+            Vf = Vf - sj;
+            welford_f32carry(st, Vf, (float)var0);
+            double t = gamma * (double)Vf;
+            Vf = (float)(t + (double)sj);
+        } else {
+            V = V - (double)sj;
+            welford_f64(st, V, var0);
+            double t = gamma * V;
+            V = t + (double)sj;
+        }
+        __threadfence_block();
+    }
+}
+
+__device__ inline bool trace_has_repeat(const GP& P, WaveLds& L, int lane, int len, const int* extra, int n_extra) {
+    // O(len^2/64) comparison of observation indices; only called when app > 1
+    bool rep = false;
+    for (int base = 0; base < len; base += 64) {
+        int i = base + lane;
+        uint32_t oi = (i < len) ? P.trace[(size_t)i * 4 + 1] : 0xFFFFFFFFu;
+        for (int j = 0; j < len; ++j) {
+            uint32_t oj = P.trace[(size_t)j * 4 + 1];
+            if (i < len && j != i && oj == oi) rep = true;
+        }
+        for (int j = 0; j < n_extra; ++j)
+            if (i < len && (uint32_t)extra[j] == oi) rep = true;
+    }
+    (void)L;
+    return __any(rep);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the back half of a simulation: ValueSim.py:83-94 / ValueSimLP.py:59-70 / agent.cpp:432-446,458
+// ---------------------------------------------------------------------------------------------------
+__device__ inline void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L, int lane) {
+    const int len = P.gs[TM_GS_TRACE_LEN];
+    const int leaf_end = P.gs[TM_GS_LEAF_END];
+    const int k = P.gs[TM_GS_K_EVAL];
+    const int leaf_score = P.gs[TM_GS_LEAF_SCORE];
+    const int kind = S.kind;
+    const bool fcarry = (kind == TM_KIND_CPPAGENT_LP || kind == TM_KIND_CPPAGENT);
+    double v0 = 0, var0 = 0;
+    int c_obs[1];
+    int n_extra = 0;
+    bool seq = false;
+    if (kind == TM_KIND_VALUESIM) {
+        v0 = (double)leaf_score;   // Python int score + np.float32 v under numpy 1.17 = float64
+        if (!leaf_end) { v0 = v0 + (double)P.eval_v[0]; var0 = (double)P.eval_var[0]; }
+    } else if (kind == TM_KIND_CPPAGENT) {
+        float ls = (float)leaf_score;   // score[trace.back()] is a float array element
+        if (!leaf_end) { v0 = (double)(ls + P.eval_v[0]); var0 = (double)P.eval_var[0]; }
+        else v0 = (double)ls;
+    } else {
+        // leaf-parallel: first-visit initialisation of the unique children, then the averaged target
+        if (S.app > 1) seq = trace_has_repeat(P, L, lane, len, P.leaf + 7, k);
+        if (k > 0) {
+            int co = (lane < k) ? P.leaf[7 + lane] : 0;
+            float cs = (lane < k) ? __int_as_float(P.leaf[14 + lane]) : 0.f;
+            uint4 st = make_uint4(0, 0, 0, 0);
+            if (lane < k) st = *reinterpret_cast<const uint4*>(P.stat + (size_t)co * 4);
+            float cval = __uint_as_float(st.y), cvar = __uint_as_float(st.z);
+            if (lane < k && st.x == 0) {
+                // core.h:344-352 tests end[child node] with the never-written arrays['end'] (ValueSimLP.py:25):
+                // always false.  agent.cpp:538 tests end_obs[o].
+                bool e = (kind == TM_KIND_CPPAGENT_LP) ? (st.w & 1u) : false;
+                cval = e ? 0.f : P.eval_v[lane];
+                cvar = e ? 0.f : P.eval_var[lane];
+                uint32_t* dst = P.stat + (size_t)co * 4;
+                dst[0] = 1u;
+                dst[1] = __float_as_uint(cval);
+                dst[2] = __float_as_uint(cvar);
+            }
+            double vt = 0, vart = 0;
+            for (int i = 0; i < k; ++i) {
+                float vi = __uint_as_float(shfl_u32(__float_as_uint(cval), i));
+                float ri = __uint_as_float(shfl_u32(__float_as_uint(cvar), i));
+                float si = __uint_as_float(shfl_u32(__float_as_uint(cs), i));
+                double gv = S.gamma * (double)vi;
+                vt = vt + ((double)si + gv);
+                vart = vart + (double)ri;
+            }
+            vt = vt / (double)k;
+            if (kind == TM_KIND_VALUESIM_LP) vart = vart * (S.gamma * S.gamma / (double)k);
+            else vart = vart / (double)k;
+            if (fcarry) { v0 = (double)(float)vt; var0 = (double)(float)vart; }
+            else { v0 = vt; var0 = vart; }
+        } else {
+            v0 = (double)(float)leaf_score;   // score_uc(trace[-1]) / (float)games[leaf].score
+            var0 = 0;
+        }
+        __threadfence_block();
+    }
+    if (S.app > 1 && kind != TM_KIND_VALUESIM_LP && kind != TM_KIND_CPPAGENT_LP)
+        seq = trace_has_repeat(P, L, lane, len, c_obs, n_extra);
+    if (seq) { if (lane == 0) lane_backup_trace_seq(S, P, len, v0, var0, fcarry); }
+    else wave_backup_trace(S, P, lane, len, v0, var0, fcarry);
+    if (lane == 0) { P.gs[TM_GS_PENDING] = 0; P.gs[TM_GS_N_SIMS] += 1; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the front half: select_trace_obs (core.h:167-224), then expansion and evaluation requests
+// ---------------------------------------------------------------------------------------------------
+__device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, int g, int lane) {
+    if (lane < 32) L.rng[lane] = S.rng[(size_t)g * 32 + lane];
+    int rng_pos = P.gs[TM_GS_RNG_POS];
+    const int rng_pos0 = rng_pos;
+    wave_sync();
+    int idx = P.gs[TM_GS_ROOT];
+    int len = 0;
+    uint32_t hdr = 0, self_o = 0;
+    const int low = S.low;
+    int nq_fallback = 0;
+    bool overflow = false;
+    for (;;) {
+        uint32_t d = (lane < TM_REC_DW) ? P.rec[(size_t)idx * TM_REC_DW + lane] : 0u;
+        hdr = shfl_u32(d, 0);
+        self_o = shfl_u32(d, 1);
+        uint32_t self_sc = shfl_u32(d, 2);
+        if (len >= S.max_trace) { overflow = true; break; }
+        if (lane == 0) reinterpret_cast<uint4*>(P.trace)[len] = make_uint4((uint32_t)idx, self_o, self_sc, 0u);
+        len += 1;
+        const int nu = (int)(hdr & 7u);
+        if (nu == 0) break;
+        const int rep = (int)((hdr >> (3 + 3 * (lane < 7 ? lane : 0))) & 7u);
+        const uint32_t c = shfl_u32(d, 3 + rep), o = shfl_u32(d, 10 + rep);
+        const float sc = __uint_as_float(shfl_u32(d, 17 + rep));
+        const bool on = lane < nu;
+        uint4 st = make_uint4(0, 0, 0, 0);
+        if (on) st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
+        const int visit = (int)st.x;
+        const uint64_t lowmask = __ballot(on && visit < low);
+        int sel;
+        if (lowmask) {
+            // check_low (core.h:65-77): a uniformly drawn under-visited child, libc rand()
+            int m = __popcll(lowmask);
+            uint32_t r = wave_rand(L, rng_pos);
+            int kth = (int)(r % (uint32_t)m);
+            uint64_t mm = lowmask;
+            for (int t = 0; t < kth; ++t) mm &= mm - 1;
+            sel = __ffsll((long long)mm) - 1;
+        } else {
+            // policy_clt (core.h:83-105): float arithmetic, one rounding per operation
+            int n = 0;
+            for (int i = 0; i < 7; ++i) { int vi = (int)shfl_u32((uint32_t)visit, i); n += (i < nu) ? vi : 0; }
+            float coeff;
+            if (n < S.nq_size) coeff = S.nq_table[n];
+            else { coeff = norm_quantile_dev((double)n); nq_fallback += 1; }
+            float value = __uint_as_float(st.y), variance = __uint_as_float(st.z);
+            float t1 = value + sc;
+            float val = t1 - __uint_as_float(self_sc);
+            float ratio = variance / (float)visit;
+            float root = sqrtf(ratio);
+            float prod = coeff * root;
+            float q = val + prod;
+            sel = 0;
+            float max_q = __uint_as_float(shfl_u32(__float_as_uint(q), 0));
+            for (int i = 1; i < 7; ++i) {
+                float qi = __uint_as_float(shfl_u32(__float_as_uint(q), i));
+                if (i < nu && qi > max_q) { max_q = qi; sel = i; }
+            }
+        }
+        idx = (int)shfl_u32(c, sel);
+    }
+    const int leaf = idx;
+    const int leaf_end = (int)((hdr >> 24) & 1u);
+    int k_eval = 0;
+    int leaf_score = (int)P.game[(size_t)leaf * GAME_DW + 14];
+    if (overflow) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_TRACE); }
+    const int kind = S.kind;
+    if (!leaf_end && !overflow) {
+        uint32_t lh;
+        wave_expand(S, P, L, g, lane, leaf, lh);
+        if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT) {
+            k_eval = 1;
+            if (lane == 0) P.eval_obs[0] = (int)self_o;
+        } else {
+            // unique children of the freshly expanded leaf (ValueSimLP.py:55 / agent.cpp:424)
+            const int nu = (int)(lh & 7u);
+            k_eval = nu;
+            if (lane < 7) {
+                int rep = (int)((lh >> (3 + 3 * lane)) & 7u);
+                bool on = lane < nu;
+                P.leaf[lane] = on ? (int)L.misc[16 + rep] : 0;
+                P.leaf[7 + lane] = on ? (int)L.misc[24 + rep] : 0;
+                P.leaf[14 + lane] = on ? (int)L.misc[32 + rep] : 0;
+                P.eval_obs[lane] = on ? (int)L.misc[24 + rep] : 0;
+            }
+        }
+        if (lane == 0) P.gs[TM_GS_N_EXPAND] += 1;
+    } else {
+        if (lane < S.eval_slots) P.eval_obs[lane] = 0;
+    }
+    if (lane == 0) {
+        P.gs[TM_GS_TRACE_LEN] = len;
+        P.gs[TM_GS_PENDING] = 1;
+        P.gs[TM_GS_LEAF] = leaf;
+        P.gs[TM_GS_LEAF_END] = leaf_end | (overflow ? 1 : 0);
+        P.gs[TM_GS_K_EVAL] = k_eval;
+        P.gs[TM_GS_LEAF_SCORE] = leaf_score;
+        if (nq_fallback) P.gs[TM_GS_N_NQ_FALLBACK] += nq_fallback;
+    }
+    if (rng_pos != rng_pos0) {
+        wave_sync();
+        if (lane < 32) S.rng[(size_t)g * 32 + lane] = L.rng[lane];
+        if (lane == 0) P.gs[TM_GS_RNG_POS] = rng_pos;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GC (agents/agent.py:206-257, ValueSim.py:101-159): reachable set from the root, free lists rebuilt in
+// ascending order, freed nodes / observations cleared, replay tuples harvested, tables rebuilt.
+// Executed by the game's own wave at the exact pop where the reference runs it.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bit_test_set(uint8_t* bm, uint32_t i) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(bm) + (i >> 5);
+    uint32_t m = 1u << (i & 31);
+    uint32_t old = atomicOr(w, m);
+    return (old & m) != 0;
+}
+__device__ __forceinline__ bool bit_test(const uint8_t* bm, uint32_t i) {
+    return (reinterpret_cast<const uint32_t*>(bm)[i >> 5] >> (i & 31)) & 1u;
+}
+
+__device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane) {
+    const int N = S.max_nodes;
+    const size_t bm_bytes = (((size_t)N + 7) / 8 + 15) & ~(size_t)15;
+    uint8_t* nmark = S.gc_mark + (size_t)g * 2 * bm_bytes;
+    uint8_t* omark = nmark + bm_bytes;
+    int32_t* queue = S.gc_queue + (size_t)g * N;
+    const uint32_t mask = (uint32_t)S.table_cap - 1u;
+    __threadfence();
+    for (size_t i = lane; i < 2 * bm_bytes / 4; i += 64) reinterpret_cast<uint32_t*>(nmark)[i] = 0;
+    __threadfence();
+    // breadth-first marking; index 0 is followed like any other child (core.h:41-45), so it stays occupied
+    int head = 0, tail = 1;
+    if (lane == 0) { queue[0] = P.gs[TM_GS_ROOT]; bit_test_set(nmark, (uint32_t)queue[0]); }
+    __threadfence();
+    while (head < tail) {
+        int i = head + lane;
+        int cnt = 0;
+        uint32_t cs[7];
+        if (i < tail) {
+            int node = queue[i];
+            bit_test_set(omark, P.rec[(size_t)node * TM_REC_DW + 1]);
+            for (int a = 0; a < 7; ++a) {
+                uint32_t c = P.rec[(size_t)node * TM_REC_DW + 3 + a];
+                if (!bit_test_set(nmark, c)) cs[cnt++] = c;
+            }
+        }
+        head = min(tail, head + 64);
+        // append this round's discoveries: exclusive scan of cnt over the wave
+        int incl = cnt;
+        for (int d = 1; d < 64; d <<= 1) {
+            int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        int total = __shfl(incl, 63, 64);
+        int off = tail + incl - cnt;
+        for (int j = 0; j < cnt; ++j) queue[off + j] = (int)cs[j];
+        tail += total;
+        __threadfence();
+    }
+    // the root of an unexpanded tree still reaches node 0 through its zero child row
+    __threadfence();
+    // free lists, ascending (agents/agent.py:211-212,221-222)
+    int nfree = 0, onfree = 0;
+    for (int base = 0; base < N; base += 64) {
+        int i = base + lane;
+        bool fr = (i < N) && !bit_test(nmark, (uint32_t)i);
+        uint64_t bm = __ballot(fr);
+        if (fr) P.fnode[nfree + __popcll(bm & ((1ull << lane) - 1ull))] = i;
+        nfree += __popcll(bm);
+        bool ofr = (i < N) && !bit_test(omark, (uint32_t)i);
+        uint64_t obm = __ballot(ofr);
+        if (ofr) P.fobs[onfree + __popcll(obm & ((1ull << lane) - 1ull))] = i;
+        onfree += __popcll(obm);
+    }
+    __threadfence();
+    // harvest replay tuples from the freed observations, ascending (ValueSim.py:122-159)
+    if (S.online && S.replay_cap > 0) {
+        int m = S.replay_count[g];
+        for (int base = 0; base < onfree; base += 64) {
+            int j = base + lane;
+            int o = (j < onfree) ? P.fobs[j] : 0;
+            uint4 st = make_uint4(0, 0, 0, 0);
+            if (j < onfree) st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
+            bool keep = (j < onfree) && ((int)st.x >= S.min_visits_to_store) && !(st.w & 1u);
+            uint64_t bm = __ballot(keep);
+            int pos = m + __popcll(bm & ((1ull << lane) - 1ull));
+            if (keep && pos < S.replay_cap) {
+                uint32_t* dk = S.replay_obs + ((size_t)g * S.replay_cap + pos) * TM_OBS_DW;
+                for (int t = 0; t < TM_OBS_DW; ++t) dk[t] = P.okey[(size_t)o * TM_OBS_DW + t];
+                float* ds = S.replay_stat + ((size_t)g * S.replay_cap + pos) * 4;
+                ds[0] = __uint_as_float(st.y); ds[1] = __uint_as_float(st.z); ds[2] = (float)(int)st.x; ds[3] = 0.f;
+            }
+            m = min(S.replay_cap, m + __popcll(bm));
+        }
+        if (lane == 0) S.replay_count[g] = m;
+    }
+    // reset_arrays (agents/agent.py:227-244): clear what was freed
+    for (int base = 0; base < nfree; base += 64) {
+        int j = base + lane;
+        if (j < nfree) {
+            int i = P.fnode[j];
+            uint4* r = reinterpret_cast<uint4*>(P.rec + (size_t)i * TM_REC_DW);
+            uint32_t keep_o = P.rec[(size_t)i * TM_REC_DW + 1];   // node_to_obs is not reset by the reference
+            for (int t = 0; t < TM_REC_DW / 4; ++t) r[t] = make_uint4(0, 0, 0, 0);
+            P.rec[(size_t)i * TM_REC_DW + 1] = keep_o;
+        }
+    }
+    for (int base = 0; base < onfree; base += 64) {
+        int j = base + lane;
+        if (j < onfree) {
+            int o = P.fobs[j];
+            *reinterpret_cast<uint4*>(P.stat + (size_t)o * 4) = make_uint4(0, 0, 0, 0);
+            uint4* k4 = reinterpret_cast<uint4*>(P.okey + (size_t)o * TM_OBS_DW);
+            k4[0] = k4[1] = k4[2] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    // rebuild both tables from what is kept
+    for (size_t i = lane; i < (size_t)S.table_cap; i += 64) { P.ntab[i] = 0; P.otab[i] = 0; }
+    __threadfence();
+    // parallel reinsertion: lanes claim empty slots with a 64-bit compare-and-swap (no deletions happen
+    // concurrently, so linear probing stays consistent; placement order does not affect lookups)
+    for (int base = 0; base < tail; base += 64) {
+        int q = base + lane;
+        int i = (q < tail) ? queue[q] : 0;
+        if (i != 0) {
+            uint32_t key[GAME_DW];
+            const uint4* src = reinterpret_cast<const uint4*>(P.game + (size_t)i * GAME_DW);
+            for (int t = 0; t < 4; ++t) { uint4 v = src[t]; key[4*t] = v.x; key[4*t+1] = v.y; key[4*t+2] = v.z; key[4*t+3] = v.w; }
+            uint64_t h = hash_game(key);
+            uint32_t s = (uint32_t)h & mask;
+            unsigned long long ent = ((h >> 32) << 32) | (uint32_t)i;
+            while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.ntab[s]), 0ull, ent) != 0ull) s = (s + 1) & mask;
+        }
+    }
+    for (int base = 0; base < N; base += 64) {
+        int o = base + lane;
+        if (o >= 1 && o < N && bit_test(omark, (uint32_t)o)) {
+            uint32_t key[OBS_DW];
+            const uint4* src = reinterpret_cast<const uint4*>(P.okey + (size_t)o * OBS_DW);
+            for (int t = 0; t < 3; ++t) { uint4 v = src[t]; key[4*t] = v.x; key[4*t+1] = v.y; key[4*t+2] = v.z; key[4*t+3] = v.w; }
+            uint64_t h = hash_obs(key);
+            uint32_t s = (uint32_t)h & mask;
+            unsigned long long ent = ((h >> 32) << 32) | (uint32_t)o;
+            while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.otab[s]), 0ull, ent) != 0ull) s = (s + 1) & mask;
+        }
+    }
+    if (lane == 0) {
+        P.gs[TM_GS_NFREE_NODE] = nfree;
+        P.gs[TM_GS_NFREE_OBS] = onfree;
+        P.gs[TM_GS_N_GC] += 1;
+    }
+    __threadfence();
+    (void)L;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags) {
+    __shared__ WaveLds lds[WPB];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WPB + w;
+    if (g >= S.n_games) return;
+    GP P = game_ptrs(S, g);
+    WaveLds& L = lds[w];
+    if ((flags & TM_SIM_BACKUP) && P.gs[TM_GS_PENDING]) {
+        wave_sim_back(S, P, L, lane);
+        __threadfence_block();
+    }
+    if (flags & TM_SIM_FRONT) wave_sim_front(S, P, L, g, lane);
+}
+
+// agent.update_root(game) (agents/agent.py:296-301)
+__global__ __launch_bounds__(64 * WPB) void k_update_root(tm_store S) {
+    __shared__ WaveLds lds[WPB];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WPB + w;
+    if (g >= S.n_games) return;
+    GP P = game_ptrs(S, g);
+    WaveLds& L = lds[w];
+    if (lane < GAME_DW) L.slots[0][lane] = S.env_game[(size_t)g * GAME_DW + lane];
+    wave_sync();
+    int idx, o;
+    wave_new_nodes(S, P, L, g, 1, lane, idx, o);
+    if (idx < 0) {
+        gc_wave(S, P, L, g, lane);   // reachable set of the OLD root, as in the reference
+        wave_new_nodes(S, P, L, g, 1, lane, idx, o);
+        if (idx < 0) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_POOL); idx = 0; }
+    }
+    if (lane == 0) {
+        P.gs[TM_GS_ROOT] = idx;
+        if ((L.slots[0][11] >> 8) & 1u) P.gs[TM_GS_EPISODE] += 1;
+    }
+}
+
+// compute_stats + get_action (agents/agent.py:153-185; agent.cpp:149-172 for the all-C++ kinds)
+__global__ void k_root_stats(tm_store S, float* stats, int32_t* action) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= S.n_games) return;
+    GP P = game_ptrs(S, g);
+    const uint32_t* r = P.rec + (size_t)P.gs[TM_GS_ROOT] * TM_REC_DW;
+    float self = __uint_as_float(r[2]);
+    float* out = stats + (size_t)g * 21;
+    const bool cpp = (S.kind == TM_KIND_CPPAGENT_LP || S.kind == TM_KIND_CPPAGENT);
+    int best = 0, first_nan = -1;
+    float bestv = 0;
+    for (int a = 0; a < 7; ++a) {
+        uint32_t o = r[10 + a];
+        float sc = __uint_as_float(r[17 + a]);
+        uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
+        float value = __uint_as_float(st.y);
+        float v1;
+        if (cpp) { float t = value + sc; v1 = t - self; }
+        else { float diff = sc - self; v1 = value + diff; }
+        out[a] = (float)(int)st.x;
+        out[7 + a] = v1;
+        out[14 + a] = __uint_as_float(st.z);
+        if (v1 != v1 && first_nan < 0) first_nan = a;
+        if (a == 0 || v1 > bestv) { if (a == 0 || v1 > bestv) { bestv = v1; best = a; } }
+    }
+    // np.argmax: first NaN wins; std::max_element (agent.cpp:170): NaN never compares greater
+    action[g] = (!cpp && first_nan >= 0) ? first_nan : best;
+}
+
+__global__ void k_pool_init(tm_store S) {
+    int g = blockIdx.x;
+    GP P = game_ptrs(S, g);
+    const int N = S.max_nodes;
+    for (int i = threadIdx.x; i < N - 1; i += blockDim.x) { P.fnode[i] = i + 1; P.fobs[i] = i + 1; }
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < TM_GS_DW; ++i) P.gs[i] = 0;
+        P.gs[TM_GS_NFREE_NODE] = N - 1;
+        P.gs[TM_GS_NFREE_OBS] = N - 1;
+        uint32_t r[32];
+        int pos;
+        srand_state(r, pos, 1u);   // the reference never calls srand(): glibc's default seed
+        for (int i = 0; i < 32; ++i) S.rng[(size_t)g * 32 + i] = r[i];
+        P.gs[TM_GS_RNG_POS] = pos;
+        if (S.replay_count) S.replay_count[g] = 0;
+    }
+}
+
+// ---- environment kernels: one lane per game, 64-byte LDS slot per lane ----
+__global__ __launch_bounds__(64) void k_env_init(tm_store S, const uint32_t* seeds) {
+    __shared__ uint32_t slots[64][GAME_DW];
+    int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= S.n_games) return;
+    EngCfg cfg{S.app, S.scoring, S.randomizer};
+    init_game(slots[threadIdx.x], cfg, seeds[g]);
+    for (int i = 0; i < GAME_DW; ++i) S.env_game[(size_t)g * GAME_DW + i] = slots[threadIdx.x][i];
+    for (int i = 0; i < 4; ++i) S.env_line_stats[(size_t)g * 4 + i] = 0;
+}
+__global__ __launch_bounds__(64) void k_env_step(tm_store S, const int32_t* actions) {
+    __shared__ uint32_t slots[64][GAME_DW];
+    int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= S.n_games) return;
+    uint32_t* sl = slots[threadIdx.x];
+    for (int i = 0; i < GAME_DW; ++i) sl[i] = S.env_game[(size_t)g * GAME_DW + i];
+    EngCfg cfg{S.app, S.scoring, S.randomizer};
+    int ls[4];
+    for (int i = 0; i < 4; ++i) ls[i] = S.env_line_stats[(size_t)g * 4 + i];
+    Piece p;
+    load_fields(sl, p);
+    // line_stats is a tiny fixed array: count through a local copy
+    int before = p.line_clears;
+    play(reinterpret_cast<uint16_t*>(sl), p, cfg, actions[g], nullptr);
+    int n = p.line_clears - before;
+    if (n > 0) ls[n - 1] += 1;
+    store_fields(sl, p);
+    for (int i = 0; i < GAME_DW; ++i) S.env_game[(size_t)g * GAME_DW + i] = sl[i];
+    for (int i = 0; i < 4; ++i) S.env_line_stats[(size_t)g * 4 + i] = ls[i];
+}
+__global__ __launch_bounds__(64) void k_env_reset(tm_store S, const uint8_t* mask) {
+    __shared__ uint32_t slots[64][GAME_DW];
+    int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= S.n_games) return;
+    uint32_t flags = (S.env_game[(size_t)g * GAME_DW + 11] >> 8) & 0xFF;
+    bool doit = mask ? (mask[g] != 0) : ((flags & 1u) != 0);
+    if (!doit) return;
+    EngCfg cfg{S.app, S.scoring, S.randomizer};
+    uint32_t seed = rnd32(S.env_game[(size_t)g * GAME_DW + 13], 0xFFFFFFFFu);
+    init_game(slots[threadIdx.x], cfg, seed);
+    for (int i = 0; i < GAME_DW; ++i) S.env_game[(size_t)g * GAME_DW + i] = slots[threadIdx.x][i];
+    for (int i = 0; i < 4; ++i) S.env_line_stats[(size_t)g * 4 + i] = 0;
+}
+__global__ void k_env_render(tm_store S, int8_t* out) {
+    __shared__ uint32_t key[OBS_DW];
+    __shared__ uint32_t gm[GAME_DW];
+    int g = blockIdx.x;
+    if (threadIdx.x < GAME_DW) gm[threadIdx.x] = S.env_game[(size_t)g * GAME_DW + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) pack_obs(gm, key);
+    __syncthreads();
+    if (threadIdx.x < 200) out[(size_t)g * 200 + threadIdx.x] = (int8_t)obs_cell(key, threadIdx.x);
+}
+__global__ void k_env_info(tm_store S, int32_t* out) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= S.n_games) return;
+    const uint32_t* e = S.env_game + (size_t)g * GAME_DW;
+    out[g * 8 + 0] = (e[11] >> 8) & 1;
+    out[g * 8 + 1] = (int)e[14];
+    out[g * 8 + 2] = (int)e[15];
+    out[g * 8 + 3] = (int)(int16_t)(e[11] >> 16);
+    for (int i = 0; i < 4; ++i) out[g * 8 + 4 + i] = S.env_line_stats[(size_t)g * 4 + i];
+}
+
+// evaluation requests -> int8 [G*K][200] observations (evaluator type 0 input, agent.cpp:424-436)
+__global__ void k_eval_render(tm_store S, int8_t* out) {
+    __shared__ uint32_t key[OBS_DW];
+    int j = blockIdx.x;
+    int g = j / S.eval_slots;
+    int o = S.eval_obs[j];
+    if (threadIdx.x < OBS_DW) key[threadIdx.x] = S.obs_key[((size_t)g * S.max_nodes + o) * OBS_DW + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 200) out[(size_t)j * 200 + threadIdx.x] = (o == 0) ? (int8_t)0 : (int8_t)obs_cell(key, threadIdx.x);
+}
+
+__global__ void k_export_game(tm_store S, int g, int32_t* child, float* score, int32_t* n_to_o, int32_t* visit,
+                              float* value, float* variance, uint8_t* end_obs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S.max_nodes) return;
+    GP P = game_ptrs(S, g);
+    const uint32_t* r = P.rec + (size_t)i * TM_REC_DW;
+    for (int a = 0; a < 7; ++a) child[(size_t)i * 7 + a] = (int)r[3 + a];
+    score[i] = __uint_as_float(r[2]);
+    n_to_o[i] = (int)r[1];
+    uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)i * 4);
+    visit[i] = (int)st.x;
+    value[i] = __uint_as_float(st.y);
+    variance[i] = __uint_as_float(st.z);
+    end_obs[i] = (uint8_t)(st.w & 1u);
+}
+
+}  // namespace tmcts
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+using namespace tmcts;
+#define TM_LAUNCH_CHECK() ((int)hipGetLastError())
+
+extern "C" {
+
+const char* tm_version(void) { return "tetris_mcts_hip 0.1 (gfx950)"; }
+
+void tm_fill_norm_quantile(float* t, int n) {
+    // special.h:26-33 with the host libm, exactly as the reference evaluates it
+    const double log2_ = log(2.0), log22 = log(22.0), log41 = log(41.0);
+    for (int i = 0; i < n; ++i) {
+        double alpha = 1 - 1 / (double)i;
+        t[i] = (float)(10 * log(1 - log(-log(alpha) / log2_) / log22) / log41);
+    }
+}
+
+int tm_pool_init(const tm_store* s, void* stream) {
+    hipLaunchKernelGGL(k_pool_init, dim3(s->n_games), dim3(256), 0, (hipStream_t)stream, *s);
+    return TM_LAUNCH_CHECK();
+}
+int tm_env_init(const tm_store* s, const uint32_t* seeds, void* stream) {
+    hipLaunchKernelGGL(k_env_init, dim3((s->n_games + 63) / 64), dim3(64), 0, (hipStream_t)stream, *s, seeds);
+    return TM_LAUNCH_CHECK();
+}
+int tm_env_step(const tm_store* s, const int32_t* actions, void* stream) {
+    hipLaunchKernelGGL(k_env_step, dim3((s->n_games + 63) / 64), dim3(64), 0, (hipStream_t)stream, *s, actions);
+    return TM_LAUNCH_CHECK();
+}
+int tm_env_reset(const tm_store* s, const uint8_t* mask, void* stream) {
+    hipLaunchKernelGGL(k_env_reset, dim3((s->n_games + 63) / 64), dim3(64), 0, (hipStream_t)stream, *s, mask);
+    return TM_LAUNCH_CHECK();
+}
+int tm_env_render(const tm_store* s, int8_t* out, void* stream) {
+    hipLaunchKernelGGL(k_env_render, dim3(s->n_games), dim3(256), 0, (hipStream_t)stream, *s, out);
+    return TM_LAUNCH_CHECK();
+}
+int tm_env_info(const tm_store* s, int32_t* out, void* stream) {
+    hipLaunchKernelGGL(k_env_info, dim3((s->n_games + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s, out);
+    return TM_LAUNCH_CHECK();
+}
+int tm_update_root(const tm_store* s, void* stream) {
+    hipLaunchKernelGGL(k_update_root, dim3((s->n_games + WPB - 1) / WPB), dim3(64 * WPB), 0, (hipStream_t)stream, *s);
+    return TM_LAUNCH_CHECK();
+}
+int tm_sim_step(const tm_store* s, int flags, void* stream) {
+    hipLaunchKernelGGL(k_sim_step, dim3((s->n_games + WPB - 1) / WPB), dim3(64 * WPB), 0, (hipStream_t)stream, *s, flags);
+    return TM_LAUNCH_CHECK();
+}
+int tm_eval_render(const tm_store* s, int8_t* out, void* stream) {
+    hipLaunchKernelGGL(k_eval_render, dim3(s->n_games * s->eval_slots), dim3(256), 0, (hipStream_t)stream, *s, out);
+    return TM_LAUNCH_CHECK();
+}
+int tm_root_stats(const tm_store* s, float* stats, int32_t* action, void* stream) {
+    hipLaunchKernelGGL(k_root_stats, dim3((s->n_games + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s, stats, action);
+    return TM_LAUNCH_CHECK();
+}
+int tm_export_game(const tm_store* s, int game, int32_t* child, float* score, int32_t* n_to_o, int32_t* visit,
+                   float* value, float* variance, uint8_t* end_obs, void* stream) {
+    hipLaunchKernelGGL(k_export_game, dim3((s->max_nodes + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s, game,
+                       child, score, n_to_o, visit, value, variance, end_obs);
+    return TM_LAUNCH_CHECK();
+}
+
+}  // extern "C"
+
+// layout self-description so the host mirror (ctypes) can be checked without a GPU
+extern "C" int tm_store_layout(int* out, int n) {
+    int v[] = {(int)sizeof(tm_store), (int)offsetof(tm_store, gamma), (int)offsetof(tm_store, node_rec),
+               (int)offsetof(tm_store, nq_table), (int)offsetof(tm_store, replay_count)};
+    int m = (int)(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; i < n && i < m; ++i) out[i] = v[i];
+    return m;
+}

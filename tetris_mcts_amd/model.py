@@ -1,0 +1,115 @@
+"""Value network of the reference (model/model_vv.py:13-52, `Net`; `Model_VV.inference` 210-217) on the GPU.
+
+Same architecture, same state_dict keys (`head.conv1.weight` ... `head.fc_out.bias`, `out_ubound`,
+`out_lbound`) and the same checkpoint dict format (`model_state_dict`, model/model.py:152-160), so the
+reference's checkpoints load unchanged.  fp32 end to end (outputs must stay within 1e-4 of the
+reference's CPU result).  Two back ends:
+  * "hip"   — tm_valuenet_forward: hand-written gfx950 kernels (fp32 MFMA), bit-identical to
+              oracle/valuenet_oracle.c's fma chains;
+  * "torch" — PyTorch-ROCm ops (MIOpen / rocBLAS), used for training and as a cross-check.
+"""
+import ctypes as C
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .store import _p, _stream
+
+PARAM_ORDER = ["head.conv1.weight", "head.conv1.bias", "head.conv2.weight", "head.conv2.bias", "head.conv3.weight",
+               "head.conv3.bias", "head.fc1.weight", "head.fc1.bias", "head.fc_out.weight", "head.fc_out.bias",
+               "out_ubound", "out_lbound"]
+EXP_PATH = "./pytorch_model/"
+variance_bound = 1e-1
+
+
+class Net(nn.Module):
+    def __init__(self, eps=variance_bound):
+        super().__init__()
+        act = nn.ReLU(inplace=True)
+        self.head = nn.Sequential(OrderedDict([
+            ("conv1", nn.Conv2d(1, 32, 3, 1, bias=True)), ("act1", act),
+            ("conv2", nn.Conv2d(32, 32, 3, 1, bias=True)), ("act2", act),
+            ("conv3", nn.Conv2d(32, 32, 3, 1, bias=True)), ("act3", act),
+            ("flatten", nn.Flatten()),
+            ("fc1", nn.Linear(32 * 14 * 4, 256)), ("fc_act1", act),
+            ("fc_out", nn.Linear(256, 2)), ("act_out", nn.Sigmoid()),
+        ]))
+        self.out_ubound = nn.Parameter(torch.tensor([1e2, 1e3]), requires_grad=False)
+        self.out_lbound = nn.Parameter(torch.tensor([0, eps]), requires_grad=False)
+
+    def forward(self, x):
+        return self.head(x) * self.out_ubound + self.out_lbound
+
+
+class Model_VV:
+    """Inference-side mirror of the reference's Model_VV (load / inference / training(False))."""
+
+    def __init__(self, backend="hip", device="cuda", seed=None, **kwargs):
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.device = torch.device(device)
+        self.model = Net().to(self.device).eval()
+        self.backend = backend
+        self._flat = None
+        self._scratch = None
+
+    def training(self, mode=True):
+        self.model.train(mode)
+
+    def load(self, filename=EXP_PATH + "model_checkpoint"):
+        if os.path.isfile(filename):
+            print("Loading model...", flush=True)
+            ck = torch.load(filename, map_location=self.device)
+            self.model.load_state_dict(ck["model_state_dict"])
+        else:
+            print("Checkpoint not found, using default model", flush=True)
+        self._flat = None
+
+    def save(self, filename=EXP_PATH + "model_checkpoint"):
+        os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
+        torch.save({"model_state_dict": self.model.state_dict(), "optimizer_state_dict": {}}, filename)
+
+    def set_flat_params(self, flat):
+        """flat: 478342 floats in PARAM_ORDER (tests/golden/ref_valuenet.npz 'params')."""
+        sd = self.model.state_dict()
+        off = 0
+        flat = torch.as_tensor(flat, dtype=torch.float32)
+        for k in PARAM_ORDER:
+            n = sd[k].numel()
+            sd[k].copy_(flat[off:off + n].reshape(sd[k].shape))
+            off += n
+        self._flat = None
+
+    def flat_params(self):
+        if self._flat is None:
+            sd = self.model.state_dict()
+            self._flat = torch.cat([sd[k].detach().reshape(-1).float() for k in PARAM_ORDER]).contiguous()
+        return self._flat
+
+    @torch.no_grad()
+    def inference_device(self, states, v_out=None, var_out=None):
+        """states: int8 [B,200] (or [B,20,10]) on the device -> (v[B], var[B]) float32 device tensors."""
+        B = states.shape[0]
+        if v_out is None:
+            v_out = torch.empty(B, dtype=torch.float32, device=self.device)
+            var_out = torch.empty(B, dtype=torch.float32, device=self.device)
+        if self.backend == "hip":
+            if self._scratch is None or self._scratch.shape[0] < B:
+                self._scratch = torch.empty(B, 9728, dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib().tm_valuenet_forward(_p(self.flat_params()), _p(states), B, _p(v_out), _p(var_out),
+                                                      _p(self._scratch), _stream()), "tm_valuenet_forward")
+        else:
+            out = self.model(states.reshape(B, 1, 20, 10).float())
+            v_out.copy_(out[:, 0])
+            var_out.copy_(out[:, 1])
+        return v_out, var_out
+
+    def inference(self, batch):
+        """Reference signature (model_vv.py:210-217): float array [B,1,20,10] -> [v[B,1], var[B,1]] numpy."""
+        b = torch.as_tensor(batch).to(self.device)
+        B = b.shape[0]
+        v, var = self.inference_device(b.reshape(B, 200).to(torch.int8).contiguous())
+        return [v.cpu().numpy().reshape(B, 1), var.cpu().numpy().reshape(B, 1)]

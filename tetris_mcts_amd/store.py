@@ -1,0 +1,132 @@
+"""Device-resident tree store (include/tetris_mcts_hip.h `tm_store`) and thin launch wrappers.
+
+PyTorch is plumbing here: device memory, the current HIP stream, and torch.distributed for sharding.
+All compute on the path goes through libtetris_mcts_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SIM_BACKUP, SIM_FRONT = 1, 2
+KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT = 0, 1, 2, 3
+GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
+          RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15)
+
+_nq_cache = {}
+
+
+def norm_quantile_table(n, device):
+    """(float)norm_quantile(i), special.h:26-33, evaluated with the host libm like the reference does."""
+    key = (n, str(device))
+    if key not in _nq_cache:
+        host = np.zeros(n, np.float32)
+        with np.errstate(all="ignore"):
+            _lib.lib().tm_fill_norm_quantile(host.ctypes.data_as(C.c_void_p), n)
+        _nq_cache[key] = torch.from_numpy(host).to(device)
+    return _nq_cache[key]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class TreeStore:
+    """Node / observation pools, transposition tables and per-game control blocks for `n_games` games."""
+
+    def __init__(self, n_games, max_nodes=100000, kind=KIND_VALUESIM, env_args=((20, 10), 1, 0, 0), gamma=0.999,
+                 low=1, eval_slots=None, max_trace=1024, nq_size=1 << 20, online=False, min_visits_to_store=10,
+                 replay_cap=0, device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("tetris_mcts_amd needs a ROCm GPU (gfx950); there is no CPU path")
+        shape, app, scoring, randomizer = env_args[0], env_args[1], env_args[2], env_args[3]
+        if tuple(shape) != (20, 10):
+            raise ValueError("only 20x10 boards are supported")
+        self.L = _lib.lib()
+        self.device = torch.device(device)
+        self.n_games, self.max_nodes, self.kind = int(n_games), int(max_nodes), int(kind)
+        if eval_slots is None:
+            eval_slots = 7 if kind in (KIND_VALUESIM_LP, KIND_CPPAGENT_LP) else 1
+        self.eval_slots = eval_slots
+        cap = 16
+        while cap < 2 * max_nodes:
+            cap <<= 1
+        G, N, dev = self.n_games, self.max_nodes, self.device
+        z = lambda *shape, dtype=torch.int32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
+        bm = ((N + 7) // 8 + 15) & ~15
+        self.t = dict(
+            node_rec=z(G, N, 24), node_game=z(G, N, 16), obs_stat=z(G, N, 4), obs_key=z(G, N, 12),
+            node_tab=z(G, cap, dtype=torch.int64), obs_tab=z(G, cap, dtype=torch.int64),
+            free_node=z(G, N), free_obs=z(G, N), gs=z(G, 16), rng=z(G, 32), env_game=z(G, 16), env_line_stats=z(G, 4),
+            trace=z(G, max_trace, 4), leaf=z(G, 32), eval_obs=z(G * eval_slots),
+            eval_v=z(G * eval_slots, dtype=torch.float32), eval_var=z(G * eval_slots, dtype=torch.float32),
+            gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N),
+            replay_obs=z(G, max(replay_cap, 1), 12), replay_stat=z(G, max(replay_cap, 1), 4, dtype=torch.float32),
+            replay_count=z(G),
+        )
+        self.t["nq_table"] = norm_quantile_table(nq_size, dev)
+        s = _lib.TmStore()
+        s.n_games, s.max_nodes, s.table_cap, s.max_trace, s.eval_slots, s.nq_size = G, N, cap, max_trace, eval_slots, nq_size
+        s.app, s.scoring, s.randomizer = int(app), int(scoring), int(randomizer)
+        s.low, s.kind, s.min_visits_to_store, s.online, s.replay_cap = int(low), int(kind), int(min_visits_to_store), int(bool(online)), int(replay_cap)
+        s.gamma = float(gamma)
+        for name, _ in _lib.TmStore._fields_[15:]:
+            setattr(s, name, self.t[name].data_ptr())
+        self.s = s
+        self.stats_buf = torch.zeros(G, 3, 7, dtype=torch.float32, device=dev)
+        self.action_buf = torch.zeros(G, dtype=torch.int32, device=dev)
+        self.eval_states = torch.zeros(G * eval_slots, 200, dtype=torch.int8, device=dev)
+        _lib.check(self.L.tm_pool_init(C.byref(s), _stream()), "tm_pool_init")
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.t.values())
+
+    # ---- tree agent entry points ----
+    def set_root_games(self, games):
+        """games: uint32/int32 [G,16] packed games (device)."""
+        self.t["env_game"].copy_(games.view(torch.int32))
+
+    def update_root(self):
+        _lib.check(self.L.tm_update_root(C.byref(self.s), _stream()), "tm_update_root")
+
+    def sim_step(self, flags):
+        _lib.check(self.L.tm_sim_step(C.byref(self.s), int(flags), _stream()), "tm_sim_step")
+
+    def render_eval(self):
+        _lib.check(self.L.tm_eval_render(C.byref(self.s), _p(self.eval_states), _stream()), "tm_eval_render")
+        return self.eval_states
+
+    def root_stats(self):
+        _lib.check(self.L.tm_root_stats(C.byref(self.s), _p(self.stats_buf), _p(self.action_buf), _stream()),
+                   "tm_root_stats")
+        return self.stats_buf, self.action_buf
+
+    def errors(self):
+        return self.t["gs"][:, GS["ERR"]]
+
+    def counter(self, name):
+        return int(self.t["gs"][:, GS[name]].sum().item())
+
+    def export_game(self, g):
+        """One game's tree in the reference's array layout (agents/agent.py:58-88), as numpy arrays."""
+        N, dev = self.max_nodes, self.device
+        out = dict(child=torch.zeros(N, 7, dtype=torch.int32, device=dev), score=torch.zeros(N, device=dev),
+                   n_to_o=torch.zeros(N, dtype=torch.int32, device=dev), visit=torch.zeros(N, dtype=torch.int32, device=dev),
+                   value=torch.zeros(N, device=dev), variance=torch.zeros(N, device=dev),
+                   end_obs=torch.zeros(N, dtype=torch.uint8, device=dev))
+        _lib.check(self.L.tm_export_game(C.byref(self.s), int(g), _p(out["child"]), _p(out["score"]), _p(out["n_to_o"]),
+                                         _p(out["visit"]), _p(out["value"]), _p(out["variance"]), _p(out["end_obs"]),
+                                         _stream()), "tm_export_game")
+        return {k: v.cpu().numpy() for k, v in out.items()}
+
+    def replay(self):
+        """Replay tuples harvested by GC (ValueSim.store_nodes, ValueSim.py:122-159): packed obs, value, variance, visit."""
+        cnt = self.t["replay_count"].clamp(max=self.s.replay_cap)
+        idx = torch.arange(self.t["replay_obs"].shape[1], device=self.device)[None, :] < cnt[:, None]
+        return self.t["replay_obs"][idx], self.t["replay_stat"][idx]
