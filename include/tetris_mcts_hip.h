@@ -24,7 +24,7 @@ extern "C" {
 #define TM_GAME_DW 16      /* packed game, ENGINE_SPEC.md section 2 (64 bytes) */
 #define TM_OBS_DW 12       /* packed observation, ENGINE_SPEC.md section 7 (48 bytes) */
 #define TM_REC_DW 24       /* node record (96 bytes), see DESIGN.md "node store" */
-#define TM_GS_DW 16        /* per-game control block */
+#define TM_GS_DW 32        /* per-game control block */
 #define TM_LEAF_DW 32      /* per-game leaf hand-off between the front and back halves of a simulation */
 #define TM_VALUENET_PARAMS 478342
 #define TM_VALUENET_SCRATCH 9728  /* floats of scratch per state for tm_valuenet_forward */
@@ -33,7 +33,9 @@ extern "C" {
 enum {
     TM_GS_ROOT = 0, TM_GS_EPISODE, TM_GS_NFREE_NODE, TM_GS_NFREE_OBS, TM_GS_TRACE_LEN, TM_GS_PENDING,
     TM_GS_ERR, TM_GS_N_EXPAND, TM_GS_N_SIMS, TM_GS_N_GC, TM_GS_RNG_POS, TM_GS_N_NQ_FALLBACK,
-    TM_GS_LEAF, TM_GS_LEAF_END, TM_GS_K_EVAL, TM_GS_LEAF_SCORE
+    TM_GS_LEAF, TM_GS_LEAF_END, TM_GS_K_EVAL, TM_GS_LEAF_SCORE,
+    TM_GS_TRACE_SUM, /* sum of trace lengths over all simulations (for bytes/simulation accounting) */
+    TM_GS_N_EVAL     /* leaf states handed to the evaluator */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
@@ -72,7 +74,7 @@ typedef struct tm_store {
     uint64_t *obs_tab;    /* [G][cap] */
     int32_t *free_node;   /* [G][N] free-index stacks (pop from the end, agents/agent.py:99) */
     int32_t *free_obs;    /* [G][N] */
-    int32_t *gs;          /* [G][16] control blocks */
+    int32_t *gs;          /* [G][TM_GS_DW] control blocks */
     uint32_t *rng;        /* [G][32] glibc rand() state (31 words) per game (core.h:62,76) */
     uint32_t *env_game;   /* [G][16] the real games */
     int32_t *env_line_stats; /* [G][4] */

@@ -644,6 +644,8 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
         P.gs[TM_GS_LEAF_END] = leaf_end | (overflow ? 1 : 0);
         P.gs[TM_GS_K_EVAL] = k_eval;
         P.gs[TM_GS_LEAF_SCORE] = leaf_score;
+        P.gs[TM_GS_TRACE_SUM] += len;
+        P.gs[TM_GS_N_EVAL] += k_eval;
         if (nq_fallback) P.gs[TM_GS_N_NQ_FALLBACK] += nq_fallback;
     }
     if (rng_pos != rng_pos0) {

@@ -13,7 +13,7 @@ from . import _lib
 SIM_BACKUP, SIM_FRONT = 1, 2
 KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT = 0, 1, 2, 3
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
-          RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15)
+          RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17)
 
 _nq_cache = {}
 
@@ -63,7 +63,7 @@ class TreeStore:
         self.t = dict(
             node_rec=z(G, N, 24), node_game=z(G, N, 16), obs_stat=z(G, N, 4), obs_key=z(G, N, 12),
             node_tab=z(G, cap, dtype=torch.int64), obs_tab=z(G, cap, dtype=torch.int64),
-            free_node=z(G, N), free_obs=z(G, N), gs=z(G, 16), rng=z(G, 32), env_game=z(G, 16), env_line_stats=z(G, 4),
+            free_node=z(G, N), free_obs=z(G, N), gs=z(G, 32), rng=z(G, 32), env_game=z(G, 16), env_line_stats=z(G, 4),
             trace=z(G, max_trace, 4), leaf=z(G, 32), eval_obs=z(G * eval_slots),
             eval_v=z(G * eval_slots, dtype=torch.float32), eval_var=z(G * eval_slots, dtype=torch.float32),
             gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N),
