@@ -27,7 +27,9 @@ extern "C" {
 #define TM_GS_DW 32        /* per-game control block */
 #define TM_LEAF_DW 32      /* per-game leaf hand-off between the front and back halves of a simulation */
 #define TM_VALUENET_PARAMS 478342
-#define TM_VALUENET_SCRATCH 9728  /* floats of scratch per state for tm_valuenet_forward */
+#define TM_VALUENET_SCRATCH 9728       /* floats of scratch per state, tm_valuenet_forward_plain */
+#define TM_VALUENET_SCRATCH_MFMA 2048  /* floats of scratch per state, tm_valuenet_forward */
+#define TM_VALUENET_PREPARED 477184    /* floats: conv2 + conv3 + fc1 operand streams */
 
 /* per-game control block (int32 words) */
 enum {
@@ -135,10 +137,17 @@ int tm_core_get_unique_child_obs(int n_trees, int n_nodes, const int32_t *index,
 int tm_core_get_all_childs(int n_trees, int n_nodes, const int32_t *roots, const int32_t *child,
                            uint8_t *mark /* [B][n_nodes] */, int32_t *queue /* [B][n_nodes] scratch */, void *stream);
 
-/* value network forward (model/model_vv.py:13-52): states int8 [B][200] -> v[B], var[B]; params as in
- * oracle/valuenet_oracle.c (PyTorch state_dict layouts).  scratch: [B][TM_VALUENET_SCRATCH] floats. */
-int tm_valuenet_forward(const float *params, const int8_t *states, int n, float *v, float *var, float *scratch,
-                        void *stream);
+/* value network forward (model/model_vv.py:13-52; Model_VV.inference 210-217): states int8 [n][200] -> v[n], var[n].
+ * params: 478342 floats in PyTorch state_dict layouts (order as in oracle/valuenet_oracle.c).
+ * tm_valuenet_prepare re-lays the conv2/conv3/fc1 weights into MFMA operand streams (call after every weight
+ * change); prepared: TM_VALUENET_PREPARED floats.  tm_valuenet_forward is the matrix-core path (scratch:
+ * n x TM_VALUENET_SCRATCH_MFMA floats); tm_valuenet_forward_plain is the one-thread-per-output form with the
+ * same fma-chain numerics (scratch: n x TM_VALUENET_SCRATCH floats).  Both are bit-identical by construction. */
+int tm_valuenet_prepare(const float *params, float *prepared, void *stream);
+int tm_valuenet_forward(const float *params, const float *prepared, const int8_t *states, int n, float *v, float *var,
+                        float *scratch, void *stream);
+int tm_valuenet_forward_plain(const float *params, const int8_t *states, int n, float *v, float *var, float *scratch,
+                              void *stream);
 
 const char *tm_version(void);
 /* sizeof(tm_store) and a few offsets, so a host mirror of the struct can be checked without a GPU */

@@ -21,7 +21,12 @@ def test_core_api_matches_reference_golden(golden_dir):
     rng = np.random.default_rng(20260925)
     dev = torch.device("cuda")
     nq = norm_quantile_table(1 << 16, dev)
-    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    keep = []  # device temporaries must outlive the asynchronous launches that read them
+
+    def d(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        keep.append(t)
+        return t
     # The golden generator interleaves rng draws with results (k depends on the trace), so replay case by case
     rng = np.random.default_rng(20260925)
     for ci in range(24):

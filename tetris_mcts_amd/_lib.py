@@ -43,7 +43,9 @@ SYMBOLS = {
     "tm_core_backup_trace_obs_lp": [i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, vp],
     "tm_core_get_unique_child_obs": [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "tm_core_get_all_childs": [i32, i32, vp, vp, vp, vp, vp],
-    "tm_valuenet_forward": [vp, vp, i32, vp, vp, vp, vp],
+    "tm_valuenet_prepare": [vp, vp, vp],
+    "tm_valuenet_forward": [vp, vp, vp, i32, vp, vp, vp, vp],
+    "tm_valuenet_forward_plain": [vp, vp, i32, vp, vp, vp, vp],
 }
 
 _lib = None

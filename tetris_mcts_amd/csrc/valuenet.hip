@@ -91,17 +91,294 @@ __global__ void k_fc_out(const float* __restrict__ h, int hstride, const float* 
     if (j == 0) v[s] = o; else var[s] = o;
 }
 
+
+// ===================================================================================================
+// MFMA path.  v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32]; lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; lane l holds D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31] in register r of 16.  Per output it is
+// the chain fma(a_k1,b_k1, fma(a_k0,b_k0, C)): stepping k in pairs, ascending, reproduces the reference order.
+// Orientation: i = output channel / hidden unit (weights are the A operand), j = output position / state.
+//
+// Prepared weights ("T4" streams): for MFMA step s the A operand of lane l is W[row=l&31][k=2s+(l>>5)];
+// four consecutive steps are stored together so one global_load_dwordx4 per lane feeds four MFMAs:
+//   T4[(s/4)*64 + l][s%4]
+// ===================================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int PREP_W2 = 0, PREP_W3 = 9216, PREP_W1 = 18432, PREP_TOTAL = 18432 + 458752;
+constexpr int A1CS = 145;   // conv1-output channel stride in LDS (18*8 = 144, +1 against bank conflicts)
+constexpr int A2CS = 97;    // conv2-output channel stride in LDS (16*6 = 96, +1)
+constexpr int WAVE_LDS = 32 * A1CS + 32 * A2CS + 200;   // floats per wave: a1, a2, input
+
+__global__ void k_vn_prepare(const float* __restrict__ P, float* __restrict__ prep) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 2 * 9216) {
+        const float* W = P + (t < 9216 ? OFF_C2W : OFF_C3W);
+        int e = t % 9216;
+        int q = e / 256, l = (e / 4) % 64, r = e % 4;
+        int s = 4 * q + r;
+        int k = 2 * s + (l >> 5), row = l & 31;
+        prep[t] = W[row * 288 + k];
+    } else if (t < PREP_TOTAL) {
+        int e = t - 18432;
+        int ht = e / (224 * 256), e2 = e % (224 * 256);
+        int q = e2 / 256, l = (e2 / 4) % 64, r = e2 % 4;
+        int s = 4 * q + r;
+        int k = 2 * s + (l >> 5), row = 32 * ht + (l & 31);
+        prep[t] = P[OFF_F1W + (size_t)row * A3 + k];
+    }
+}
+
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 3x3 valid convolution, 32 -> 32 channels, as TILES position tiles of 32 on the matrix cores.
+// in: LDS activations [32][IN_CS] (rows of IN_W), boff[t][j]: this lane's LDS float offset for tile t and the
+// j-th step of an 18-k (two input channel) block; W: prepared T4 stream (+lane already applied).
+template <int TILES, int IN_CS>
+__device__ __forceinline__ void conv_mfma(const float* __restrict__ in, const int (&boff)[TILES][9],
+                                          const float4* __restrict__ W, f32x16 (&acc)[TILES]) {
+    // Software pipeline: the B operands (LDS) of quad q+1 and the weights (global) of quad q+2 are requested
+    // while the 4*TILES MFMAs of quad q issue; accumulators rotate so consecutive MFMAs are independent.
+    float4 wq[3];
+    float bb[2][4][TILES];
+    auto load_b = [&](int q, int buf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = 4 * q + r, cp = s / 9, j = s % 9;   // 18 k per pair of input channels
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) bb[buf][r][t] = in[boff[t][j] + cp * 2 * IN_CS];
+        }
+    };
+    wq[0] = W[0];
+    wq[1] = W[64];
+    load_b(0, 0);
+#pragma unroll
+    for (int q = 0; q < 36; ++q) {
+        if (q + 2 < 36) wq[(q + 2) % 3] = W[(q + 2) * 64];
+        if (q + 1 < 36) load_b(q + 1, (q + 1) & 1);
+        const float4 w4 = wq[q % 3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = (r == 0) ? w4.x : (r == 1) ? w4.y : (r == 2) ? w4.z : w4.w;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[q & 1][r][t], acc[t], 0, 0, 0);
+        }
+        // issue order inside the quad: one LDS read behind every MFMA, the weight load up front
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+        for (int i = 0; i < 4 * TILES; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_vn_conv(const float* __restrict__ P, const float* __restrict__ prep,
+                                                    const int8_t* __restrict__ states, int n, float* __restrict__ a3out,
+                                                    int a3stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+    float* a1 = smem + w * WAVE_LDS;
+    float* a2 = a1 + 32 * A1CS;
+    float* x0 = a2 + 32 * A2CS;
+    // ---- per-lane constants ----
+    int koff2[9], koff3[9];   // offsets of k = 2j+half inside a two-channel block
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        int k = 2 * j + half, ci = k / 9, r = k - 9 * ci, ky = r / 3, kx = r - 3 * ky;
+        koff2[j] = ci * A1CS + ky * 8 + kx;
+        koff3[j] = ci * A2CS + ky * 6 + kx;
+    }
+    int boff2[3][9], boff3[2][9];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        int p = 32 * t + l31, y = p / 6, x = p - 6 * y;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) boff2[t][j] = y * 8 + x + koff2[j];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int p = min(32 * t + l31, 55), y = p / 4, x = p - 4 * y;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) boff3[t][j] = y * 6 + x + koff3[j];
+    }
+    float bias2[16], bias3[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        bias2[r] = P[OFF_C2B + i];
+        bias3[r] = P[OFF_C3B + i];
+    }
+    const float4* W2 = reinterpret_cast<const float4*>(prep + PREP_W2) + lane;
+    const float4* W3 = reinterpret_cast<const float4*>(prep + PREP_W3) + lane;
+
+    for (int s = blockIdx.x * 4 + w; s < n; s += gridDim.x * 4) {
+        // ---- input ----
+        for (int i = lane; i < 200; i += 64) x0[i] = (float)states[(size_t)s * 200 + i];
+        lds_fence();
+        // ---- conv1 on the vector ALUs: lanes = output positions (18x8), weights as scalars ----
+        {
+            float xin[3][9];
+            int pp[3];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                int p = lane + 64 * jj;
+                pp[jj] = p;
+                int pc = min(p, 143), y = pc >> 3, x = pc & 7;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) xin[jj][ky * 3 + kx] = x0[(y + ky) * 10 + x + kx];
+            }
+#pragma unroll 1
+            for (int co = 0; co < 32; ++co) {
+                const float* wc = P + OFF_C1W + co * 9;
+                const float b = P[OFF_C1B + co];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    float acc = b;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) acc = fmaf(xin[jj][k], wc[k], acc);
+                    if (pp[jj] < 144) a1[co * A1CS + pp[jj]] = acc > 0.0f ? acc : 0.0f;
+                }
+            }
+        }
+        lds_fence();
+        // ---- conv2: 96 positions = 3 tiles ----
+        {
+            f32x16 acc[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = bias2[r];
+            conv_mfma<3, A1CS>(a1, boff2, W2, acc);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[t][r];
+                    a2[i * A2CS + 32 * t + l31] = v > 0.0f ? v : 0.0f;
+                }
+        }
+        lds_fence();
+        // ---- conv3: 56 positions = 2 tiles (the last 8 lanes of tile 1 are padding) ----
+        {
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = bias3[r];
+            conv_mfma<2, A2CS>(a2, boff3, W3, acc);
+            float* dst = a3out + (size_t)s * a3stride;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                int p = 32 * t + l31;
+                if (p < 56) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float v = acc[t][r];
+                        dst[i * 56 + p] = v > 0.0f ? v : 0.0f;
+                    }
+                }
+            }
+        }
+        lds_fence();
+    }
+}
+
+// fc1 (1792 -> 256) + ReLU: a workgroup owns 32 states x 128 hidden units (one 32x32 accumulator per wave).
+constexpr int FC_KC = 64, FC_PITCH = FC_KC + 1;
+__global__ __launch_bounds__(256) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
+                                                const float* __restrict__ a3, int a3stride, int n,
+                                                float* __restrict__ hout, int hstride) {
+    __shared__ float bt[2][32 * FC_PITCH];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+    const int s0 = blockIdx.x * 32;
+    const int ht = blockIdx.y * 4 + w;   // hidden tile 0..7
+    const float4* W = reinterpret_cast<const float4*>(prep + PREP_W1) + (size_t)ht * 224 * 64 + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = P[OFF_F1B + 32 * ht + (r & 3) + 8 * (r >> 2) + 4 * half];
+    // staging: 32 rows x 64 floats per chunk = 512 float4, two per thread
+    const int row0 = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;   // rows row0 and row0+16
+    float4 st0, st1;
+    auto gload = [&](int chunk) {
+        int sa = s0 + row0, sb = s0 + row0 + 16;
+        st0 = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4) : make_float4(0, 0, 0, 0);
+        st1 = (sb < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sb * a3stride + chunk * FC_KC + c4) : make_float4(0, 0, 0, 0);
+    };
+    auto lstore = [&](int buf) {
+        float* d0 = &bt[buf][row0 * FC_PITCH + c4];
+        d0[0] = st0.x; d0[1] = st0.y; d0[2] = st0.z; d0[3] = st0.w;
+        float* d1 = &bt[buf][(row0 + 16) * FC_PITCH + c4];
+        d1[0] = st1.x; d1[1] = st1.y; d1[2] = st1.z; d1[3] = st1.w;
+    };
+    constexpr int NCH = A3 / FC_KC;   // 28 chunks of 64 k = 32 MFMA steps = 8 weight quads
+    float4 wbuf[2][8];
+    auto wload = [&](int chunk, int buf) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wbuf[buf][q] = W[((size_t)chunk * 8 + q) * 64];
+    };
+    gload(0);
+    wload(0, 0);
+    lstore(0);
+    __syncthreads();
+#pragma unroll 2
+    for (int c = 0; c < NCH; ++c) {
+        // requests for the next chunk (activations -> registers, weights -> the other register buffer) go out first
+        if (c + 1 < NCH) { gload(c + 1); wload(c + 1, (c + 1) & 1); }
+        const float* b = &bt[c & 1][l31 * FC_PITCH + half];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 w4 = wbuf[c & 1][q];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, b[2 * (4 * q + 0)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, b[2 * (4 * q + 1)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, b[2 * (4 * q + 2)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, b[2 * (4 * q + 3)], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);   // the 10 global loads lead the chunk
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (c + 1 < NCH) lstore((c + 1) & 1);
+        __syncthreads();
+    }
+    const int sj = s0 + l31;
+    if (sj < n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int i = 32 * ht + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[r];
+            hout[(size_t)sj * hstride + i] = v > 0.0f ? v : 0.0f;
+        }
+    }
+}
+
 }  // namespace tmcts_vn
 
 using namespace tmcts_vn;
 
-extern "C" int tm_valuenet_forward(const float* P, const int8_t* states, int n, float* v, float* var, float* scratch,
-                                   void* stream_) {
-    // scratch: n x TM_VALUENET_SCRATCH floats
+extern "C" {
+
+int tm_valuenet_prepare(const float* P, float* prepared, void* stream_) {
+    hipLaunchKernelGGL(k_vn_prepare, dim3((PREP_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, prepared);
+    return (int)hipGetLastError();
+}
+
+// reference-order plain kernels (one thread per output); scratch: n x TM_VALUENET_SCRATCH floats
+int tm_valuenet_forward_plain(const float* P, const int8_t* states, int n, float* v, float* var, float* scratch,
+                              void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n <= 0) return 0;
     constexpr int SS = TM_VALUENET_SCRATCH;
-    float* a1 = scratch;            // [n][SS]: a1 at 0, a2 at A1, a3 at A1+A2, h at A1+A2+A3
+    float* a1 = scratch;            // per state: a1 at 0, a2 at A1, a3 at A1+A2, h at A1+A2+A3
     const int T = 256;
     hipLaunchKernelGGL((k_conv3x3_relu<1, 20, 10>), dim3((n * A1 + T - 1) / T), dim3(T), 0, stream, (const float*)nullptr,
                        0, states, P + OFF_C1W, P + OFF_C1B, a1, SS, n);
@@ -114,3 +391,26 @@ extern "C" int tm_valuenet_forward(const float* P, const int8_t* states, int n, 
     hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + T - 1) / T), dim3(T), 0, stream, a1 + A1 + A2 + A3, SS, P, v, var, n);
     return (int)hipGetLastError();
 }
+
+// matrix-core path; prepared: tm_valuenet_prepare output; scratch: n x TM_VALUENET_SCRATCH_MFMA floats
+int tm_valuenet_forward(const float* P, const float* prepared, const int8_t* states, int n, float* v, float* var,
+                        float* scratch, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0) return 0;
+    constexpr int SS = TM_VALUENET_SCRATCH_MFMA;   // a3 (1792) + hidden (256)
+    static bool attr_set = false;
+    const int lds = 4 * WAVE_LDS * (int)sizeof(float);
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vn_conv), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    int blocks = (n + 3) / 4;
+    if (blocks > 256) blocks = 256;   // one workgroup per CU, waves stride over the states
+    hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, n, scratch, SS);
+    hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(256), 0, stream, P, prepared, scratch, SS, n,
+                       scratch + A3, SS);
+    hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, v, var, n);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

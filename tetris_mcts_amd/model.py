@@ -54,6 +54,7 @@ class Model_VV:
         self.model = Net().to(self.device).eval()
         self.backend = backend
         self._flat = None
+        self._prepared = None
         self._scratch = None
 
     def training(self, mode=True):
@@ -67,6 +68,7 @@ class Model_VV:
         else:
             print("Checkpoint not found, using default model", flush=True)
         self._flat = None
+        self._prepared = None
 
     def save(self, filename=EXP_PATH + "model_checkpoint"):
         os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
@@ -82,6 +84,7 @@ class Model_VV:
             sd[k].copy_(flat[off:off + n].reshape(sd[k].shape))
             off += n
         self._flat = None
+        self._prepared = None
 
     def flat_params(self):
         if self._flat is None:
@@ -98,9 +101,18 @@ class Model_VV:
             var_out = torch.empty(B, dtype=torch.float32, device=self.device)
         if self.backend == "hip":
             if self._scratch is None or self._scratch.shape[0] < B:
-                self._scratch = torch.empty(B, 9728, dtype=torch.float32, device=self.device)
-            _lib.check(_lib.lib().tm_valuenet_forward(_p(self.flat_params()), _p(states), B, _p(v_out), _p(var_out),
+                self._scratch = torch.empty(B, 2048, dtype=torch.float32, device=self.device)
+            P = self.flat_params()
+            if self._prepared is None:
+                self._prepared = torch.empty(477184, dtype=torch.float32, device=self.device)
+                _lib.check(_lib.lib().tm_valuenet_prepare(_p(P), _p(self._prepared), _stream()), "tm_valuenet_prepare")
+            _lib.check(_lib.lib().tm_valuenet_forward(_p(P), _p(self._prepared), _p(states), B, _p(v_out), _p(var_out),
                                                       _p(self._scratch), _stream()), "tm_valuenet_forward")
+        elif self.backend == "hip_plain":
+            if self._scratch is None or self._scratch.shape[0] < B:
+                self._scratch = torch.empty(B, 9728, dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib().tm_valuenet_forward_plain(_p(self.flat_params()), _p(states), B, _p(v_out), _p(var_out),
+                                                            _p(self._scratch), _stream()), "tm_valuenet_forward_plain")
         else:
             out = self.model(states.reshape(B, 1, 20, 10).float())
             v_out.copy_(out[:, 0])
