@@ -92,8 +92,7 @@ def main():
                 e[0].record()
                 S.sim_step(st.SIM_BACKUP | st.SIM_FRONT)
                 e[1].record()
-                states = S.render_eval()
-                agent.evaluate(states, S.t["eval_v"], S.t["eval_var"])
+                agent.evaluate_requests()
                 e[2].record()
             S.sim_step(st.SIM_BACKUP)
         _, action = S.root_stats()

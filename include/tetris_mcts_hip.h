@@ -146,6 +146,10 @@ int tm_core_get_all_childs(int n_trees, int n_nodes, const int32_t *roots, const
 int tm_valuenet_prepare(const float *params, float *prepared, void *stream);
 int tm_valuenet_forward(const float *params, const float *prepared, const int8_t *states, int n, float *v, float *var,
                         float *scratch, void *stream);
+/* evaluate the tree engine's pending requests (s->eval_obs) and write s->eval_v / s->eval_var; the packed
+ * observations are rendered inside the first kernel (no int8 staging).  scratch: G*eval_slots x TM_VALUENET_SCRATCH_MFMA */
+int tm_valuenet_forward_requests(const float *params, const float *prepared, const tm_store *s, float *scratch,
+                                 void *stream);
 int tm_valuenet_forward_plain(const float *params, const int8_t *states, int n, float *v, float *var, float *scratch,
                               void *stream);
 

@@ -46,6 +46,7 @@ SYMBOLS = {
     "tm_valuenet_prepare": [vp, vp, vp],
     "tm_valuenet_forward": [vp, vp, vp, i32, vp, vp, vp, vp],
     "tm_valuenet_forward_plain": [vp, vp, i32, vp, vp, vp, vp],
+    "tm_valuenet_forward_requests": [vp, vp, C.POINTER(TmStore), vp, vp],
 }
 
 _lib = None

@@ -35,3 +35,9 @@ class ValueSim(TreeAgent):
             var_out.copy_(var)
         else:
             self.model.inference_device(states, v_out, var_out)
+
+    def evaluate_requests(self):
+        if self.evaluator is None and self.model.backend == "hip":
+            self.model.inference_requests(self.store)   # observations rendered inside the conv kernel
+        else:
+            super().evaluate_requests()

@@ -68,11 +68,16 @@ class TreeAgent(Agent):
     def evaluate(self, states, v_out, var_out):
         raise NotImplementedError('evaluate not implemented for this agent.')
 
-    def _sim_body(self):
+    def evaluate_requests(self):
+        """Evaluate the store's pending leaf requests into eval_v / eval_var.  Default: render the observations
+        to int8 [B,200] and call evaluate(); agents with the HIP value net override this with the fused path."""
         s = self.store
-        s.sim_step(st.SIM_BACKUP | st.SIM_FRONT)
         states = s.render_eval()
         self.evaluate(states, s.t["eval_v"], s.t["eval_var"])
+
+    def _sim_body(self):
+        self.store.sim_step(st.SIM_BACKUP | st.SIM_FRONT)
+        self.evaluate_requests()
 
     def mcts(self, sims):
         s = self.store

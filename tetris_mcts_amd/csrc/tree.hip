@@ -18,6 +18,7 @@
 namespace tmcts {
 
 constexpr int WPB = 4;  // wavefronts (games) per workgroup
+constexpr int NQ_LDS = 2048;  // entries of nq_table mirrored in LDS (child-visit sums are mostly small)
 
 struct WaveLds {
     uint32_t slots[8][GAME_DW];  // 0..6 successor games, 7 the parent
@@ -547,7 +548,7 @@ __device__ inline void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L,
 // ---------------------------------------------------------------------------------------------------
 // the front half: select_trace_obs (core.h:167-224), then expansion and evaluation requests
 // ---------------------------------------------------------------------------------------------------
-__device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, int g, int lane) {
+__device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, const float* nq_lds, int g, int lane) {
     if (lane < 32) L.rng[lane] = S.rng[(size_t)g * 32 + lane];
     int rng_pos = P.gs[TM_GS_RNG_POS];
     const int rng_pos0 = rng_pos;
@@ -558,8 +559,14 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
     const int low = S.low;
     int nq_fallback = 0;
     bool overflow = false;
+    // Each level needs the node record and then the statistics of its <=7 unique child observations.  The
+    // records of those children are requested together with the statistics (168 dwords = 3 loads per lane), so
+    // the record of whichever child gets selected is already in registers: one memory round trip per level.
+    int pf_child[3], pf_word[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { int e = lane + 64 * r; pf_child[r] = e / TM_REC_DW; pf_word[r] = e - pf_child[r] * TM_REC_DW; }
+    uint32_t d = (lane < TM_REC_DW) ? P.rec[(size_t)idx * TM_REC_DW + lane] : 0u;
     for (;;) {
-        uint32_t d = (lane < TM_REC_DW) ? P.rec[(size_t)idx * TM_REC_DW + lane] : 0u;
         hdr = shfl_u32(d, 0);
         self_o = shfl_u32(d, 1);
         uint32_t self_sc = shfl_u32(d, 2);
@@ -574,6 +581,12 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
         const bool on = lane < nu;
         uint4 st = make_uint4(0, 0, 0, 0);
         if (on) st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
+        uint32_t pre[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            uint32_t cc = shfl_u32(c, pf_child[r] < 7 ? pf_child[r] : 0);
+            pre[r] = (pf_child[r] < nu) ? P.rec[(size_t)cc * TM_REC_DW + pf_word[r]] : 0u;
+        }
         const int visit = (int)st.x;
         const uint64_t lowmask = __ballot(on && visit < low);
         int sel;
@@ -590,7 +603,8 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
             int n = 0;
             for (int i = 0; i < 7; ++i) { int vi = (int)shfl_u32((uint32_t)visit, i); n += (i < nu) ? vi : 0; }
             float coeff;
-            if (n < S.nq_size) coeff = S.nq_table[n];
+            if (n < NQ_LDS && n < S.nq_size) coeff = nq_lds[n];
+            else if (n < S.nq_size) coeff = S.nq_table[n];
             else { coeff = norm_quantile_dev((double)n); nq_fallback += 1; }
             float value = __uint_as_float(st.y), variance = __uint_as_float(st.z);
             float t1 = value + sc;
@@ -607,6 +621,12 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
             }
         }
         idx = (int)shfl_u32(c, sel);
+        {   // the selected child's record out of the prefetched block
+            int e = sel * TM_REC_DW + (lane < TM_REC_DW ? lane : 0);
+            uint32_t v0 = shfl_u32(pre[0], e & 63), v1 = shfl_u32(pre[1], e & 63), v2 = shfl_u32(pre[2], e & 63);
+            int r = e >> 6;
+            d = (lane < TM_REC_DW) ? (r == 0 ? v0 : (r == 1 ? v1 : v2)) : 0u;
+        }
     }
     const int leaf = idx;
     const int leaf_end = (int)((hdr >> 24) & 1u);
@@ -810,8 +830,13 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags) {
     __shared__ WaveLds lds[WPB];
+    __shared__ float nq_lds[NQ_LDS];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = blockIdx.x * WPB + w;
+    if (flags & TM_SIM_FRONT) {
+        for (int i = threadIdx.x; i < NQ_LDS; i += 64 * WPB) nq_lds[i] = (i < S.nq_size) ? S.nq_table[i] : 0.f;
+        __syncthreads();
+    }
     if (g >= S.n_games) return;
     GP P = game_ptrs(S, g);
     WaveLds& L = lds[w];
@@ -819,7 +844,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         wave_sim_back(S, P, L, lane);
         __threadfence_block();
     }
-    if (flags & TM_SIM_FRONT) wave_sim_front(S, P, L, g, lane);
+    if (flags & TM_SIM_FRONT) wave_sim_front(S, P, L, nq_lds, g, lane);
 }
 
 // agent.update_root(game) (agents/agent.py:296-301)

@@ -176,9 +176,13 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, const in
     }
 }
 
+// Input: either int8 states [n][200], or (states == nullptr) evaluation requests of the tree engine:
+// request s refers to packed observation eval_obs[s] of game s / eval_slots (ENGINE_SPEC.md section 7), rendered
+// here on the fly (0 empty, 1 locked, -1 falling piece; request 0 = unused slot = empty board).
 __global__ __launch_bounds__(256, 1) void k_vn_conv(const float* __restrict__ P, const float* __restrict__ prep,
-                                                    const int8_t* __restrict__ states, int n, float* __restrict__ a3out,
-                                                    int a3stride) {
+                                                    const int8_t* __restrict__ states, const uint32_t* __restrict__ obs_key,
+                                                    const int32_t* __restrict__ eval_obs, int eval_slots, int max_nodes,
+                                                    int n, float* __restrict__ a3out, int a3stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
     float* a1 = smem + w * WAVE_LDS;
@@ -217,7 +221,23 @@ __global__ __launch_bounds__(256, 1) void k_vn_conv(const float* __restrict__ P,
 
     for (int s = blockIdx.x * 4 + w; s < n; s += gridDim.x * 4) {
         // ---- input ----
-        for (int i = lane; i < 200; i += 64) x0[i] = (float)states[(size_t)s * 200 + i];
+        if (states) {
+            for (int i = lane; i < 200; i += 64) x0[i] = (float)states[(size_t)s * 200 + i];
+        } else {
+            const int o = eval_obs[s];
+            const uint32_t* key = obs_key + ((size_t)(s / eval_slots) * max_nodes + o) * 12;
+            uint32_t kw = (lane < 12) ? key[lane] : 0u;
+            const uint32_t cells = __shfl((int)kw, 10, 64), endw = __shfl((int)kw, 11, 64);
+            for (int i = lane; i < 200; i += 64) {
+                int r = i / 10, c = i - 10 * r;
+                uint32_t w2 = (uint32_t)__shfl((int)kw, r >> 1, 64);
+                float v = (float)((w2 >> (16 * (r & 1) + c)) & 1u);
+                bool pc = ((cells & 0xFF) == (uint32_t)i) | (((cells >> 8) & 0xFF) == (uint32_t)i) |
+                          (((cells >> 16) & 0xFF) == (uint32_t)i) | ((cells >> 24) == (uint32_t)i);
+                if (!(endw & 0xFFu) && pc) v = -1.0f;
+                x0[i] = (o == 0) ? 0.0f : v;
+            }
+        }
         lds_fence();
         // ---- conv1 on the vector ALUs: lanes = output positions (18x8), weights as scalars ----
         {
@@ -361,6 +381,38 @@ __global__ __launch_bounds__(256) void k_vn_fc1(const float* __restrict__ P, con
     }
 }
 
+
+// fc_out (256 -> 2) + sigmoid + affine for 32 states per workgroup: hidden rows staged in LDS, one lane per
+// (state, output) walks the 256-term fma chain in order.
+__global__ __launch_bounds__(64) void k_vn_fcout(const float* __restrict__ h, int hstride, const float* __restrict__ P,
+                                                 float* __restrict__ v, float* __restrict__ var, int n) {
+    __shared__ float hs[32 * 257];
+    __shared__ float ws[512];
+    const int t = threadIdx.x, s0 = blockIdx.x * 32;
+    for (int i = t; i < 512; i += 64) ws[i] = P[OFF_FOW + i];
+    for (int e = t; e < 32 * 64; e += 64) {
+        int row = e >> 6, c4 = (e & 63) * 4;
+        float4 x = (s0 + row < n) ? *reinterpret_cast<const float4*>(h + (size_t)(s0 + row) * hstride + c4)
+                                  : make_float4(0, 0, 0, 0);
+        float* d = &hs[row * 257 + c4];
+        d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+    }
+    __syncthreads();
+    const int j = t & 31, o = t >> 5;
+    float acc = P[OFF_FOB + o];
+    const float* x = &hs[j * 257];
+    const float* wr = &ws[o * 256];
+#pragma unroll 8
+    for (int i = 0; i < HID; ++i) acc = fmaf(x[i], wr[i], acc);
+    if (s0 + j < n) {
+        double e = tm_exp(-(double)acc);
+        float sg = (float)(1.0 / (1.0 + e));
+        float tt = sg * P[OFF_UB + o];
+        float r = tt + P[OFF_LB + o];
+        if (o == 0) v[s0 + j] = r; else var[s0 + j] = r;
+    }
+}
+
 }  // namespace tmcts_vn
 
 using namespace tmcts_vn;
@@ -392,25 +444,39 @@ int tm_valuenet_forward_plain(const float* P, const int8_t* states, int n, float
     return (int)hipGetLastError();
 }
 
-// matrix-core path; prepared: tm_valuenet_prepare output; scratch: n x TM_VALUENET_SCRATCH_MFMA floats
-int tm_valuenet_forward(const float* P, const float* prepared, const int8_t* states, int n, float* v, float* var,
-                        float* scratch, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int vn_forward_impl(const float* P, const float* prepared, const int8_t* states, const uint32_t* obs_key,
+                           const int32_t* eval_obs, int eval_slots, int max_nodes, int n, float* v, float* var,
+                           float* scratch, hipStream_t stream) {
     if (n <= 0) return 0;
     constexpr int SS = TM_VALUENET_SCRATCH_MFMA;   // a3 (1792) + hidden (256)
     static bool attr_set = false;
     const int lds = 4 * WAVE_LDS * (int)sizeof(float);
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vn_conv), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_vn_conv),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     int blocks = (n + 3) / 4;
     if (blocks > 256) blocks = 256;   // one workgroup per CU, waves stride over the states
-    hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, n, scratch, SS);
+    hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, eval_obs,
+                       eval_slots, max_nodes, n, scratch, SS);
     hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(256), 0, stream, P, prepared, scratch, SS, n,
                        scratch + A3, SS);
-    hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, v, var, n);
+    hipLaunchKernelGGL(k_vn_fcout, dim3((n + 31) / 32), dim3(64), 0, stream, scratch + A3, SS, P, v, var, n);
     return (int)hipGetLastError();
+}
+
+// matrix-core path; prepared: tm_valuenet_prepare output; scratch: n x TM_VALUENET_SCRATCH_MFMA floats
+int tm_valuenet_forward(const float* P, const float* prepared, const int8_t* states, int n, float* v, float* var,
+                        float* scratch, void* stream_) {
+    return vn_forward_impl(P, prepared, states, nullptr, nullptr, 1, 0, n, v, var, scratch, (hipStream_t)stream_);
+}
+
+// the tree engine's evaluation requests, rendered inside the first kernel: v/var -> s->eval_v / s->eval_var
+int tm_valuenet_forward_requests(const float* P, const float* prepared, const tm_store* s, float* scratch, void* stream_) {
+    return vn_forward_impl(P, prepared, nullptr, s->obs_key, s->eval_obs, s->eval_slots, s->max_nodes,
+                           s->n_games * s->eval_slots, s->eval_v, s->eval_var, scratch, (hipStream_t)stream_);
 }
 
 }  // extern "C"

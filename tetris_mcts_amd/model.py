@@ -119,6 +119,20 @@ class Model_VV:
             var_out.copy_(out[:, 1])
         return v_out, var_out
 
+    @torch.no_grad()
+    def inference_requests(self, store):
+        """Evaluate a TreeStore's pending leaf requests in place (fused render + forward, HIP back end only)."""
+        import ctypes as C
+        B = store.n_games * store.eval_slots
+        if self._scratch is None or self._scratch.shape[0] < B or self._scratch.shape[1] < 2048:
+            self._scratch = torch.empty(B, 2048, dtype=torch.float32, device=self.device)
+        P = self.flat_params()
+        if self._prepared is None:
+            self._prepared = torch.empty(477184, dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib().tm_valuenet_prepare(_p(P), _p(self._prepared), _stream()), "tm_valuenet_prepare")
+        _lib.check(_lib.lib().tm_valuenet_forward_requests(_p(P), _p(self._prepared), C.byref(store.s),
+                                                           _p(self._scratch), _stream()), "tm_valuenet_forward_requests")
+
     def inference(self, batch):
         """Reference signature (model_vv.py:210-217): float array [B,1,20,10] -> [v[B,1], var[B,1]] numpy."""
         b = torch.as_tensor(batch).to(self.device)
