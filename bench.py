@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--max-nodes", type=int, default=100000)
     ap.add_argument("--backend", default="hip", choices=["hip", "torch"])
     ap.add_argument("--graph", action="store_true", help="replay the simulation body as a hipGraph (no per-kernel events)")
+    ap.add_argument("--split", type=int, default=1, help="run the rank's games as this many independent sub-batches on "
+                    "separate HIP streams, so one sub-batch's tree kernel overlaps another's value-net kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -66,18 +68,28 @@ def main():
     from tetris_mcts_amd.pyTetris import Tetris
 
     G, sims = args.games, args.sims
+    NS = args.split
+    assert G % NS == 0
+    Gs = G // NS
     env_args = ((20, 10), 1, 0, 0)
     model = Model_VV(backend=args.backend, seed=0)  # model_vv.Net() under torch.manual_seed(0) (random init)
     base_seed = 20260925 + rank * G
-    game = Tetris(*env_args, seed=base_seed, n_games=G)
-    agent = getattr(agents, args.agent)(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=args.max_nodes,
-                                        model=model, online=False, use_graph=args.graph)
-    agent.update_root(game)
-    S = agent.store
-    dev = S.device
-    K = S.eval_slots
+    streams = [torch.cuda.Stream() for _ in range(NS)] if NS > 1 else [torch.cuda.current_stream()]
+    games, agts, models = [], [], []
+    for k in range(NS):
+        with torch.cuda.stream(streams[k]):
+            mk = model if k == 0 else Model_VV(backend=args.backend, seed=0)   # own scratch per stream, same weights
+            game = Tetris(*env_args, seed=base_seed + k * Gs, n_games=Gs)
+            agent = getattr(agents, args.agent)(sims=sims, env=Tetris, env_args=env_args, n_games=Gs,
+                                                max_nodes=args.max_nodes, model=mk, online=False, use_graph=args.graph)
+            agent.update_root(game)
+        games.append(game); agts.append(agent); models.append(mk)
+    torch.cuda.synchronize()
+    stores = [a.store for a in agts]
+    dev = stores[0].device
+    K = stores[0].eval_slots
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(sims)] if not args.graph else None
+    ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(sims)] for _ in range(NS)] if not args.graph else None
     t_tree = t_nn = 0.0
     n_tree = n_nn = 0
     episodes, lines = 0, 0
@@ -85,39 +97,51 @@ def main():
     def one_step(timed):
         nonlocal t_tree, t_nn, n_tree, n_nn, episodes, lines
         if args.graph:
-            agent.mcts(sims)
+            for k in range(NS):
+                with torch.cuda.stream(streams[k]):
+                    agts[k].mcts(sims)
         else:
             for i in range(sims):
-                e = ev[i]
-                e[0].record()
-                S.sim_step(st.SIM_BACKUP | st.SIM_FRONT)
-                e[1].record()
-                agent.evaluate_requests()
-                e[2].record()
-            S.sim_step(st.SIM_BACKUP)
-        _, action = S.root_stats()
-        game.play(action)
-        agent.update_root(game)          # reads game.end: one small host sync per move, as the reference's loop has
-        ended = np.atleast_1d(game.end)
-        if ended.any():
-            episodes += int(ended.sum())
-            lines += int(np.atleast_1d(game.line_clears)[ended].sum())
-            game.reset("ended")
-            agent.update_root(game)
+                for k in range(NS):
+                    with torch.cuda.stream(streams[k]):
+                        e = ev[k][i]
+                        e[0].record()
+                        stores[k].sim_step(st.SIM_BACKUP | st.SIM_FRONT)
+                        e[1].record()
+                        agts[k].evaluate_requests()
+                        e[2].record()
+            for k in range(NS):
+                with torch.cuda.stream(streams[k]):
+                    stores[k].sim_step(st.SIM_BACKUP)
+        for k in range(NS):
+            with torch.cuda.stream(streams[k]):
+                _, action = stores[k].root_stats()
+                games[k].play(action)
+                agts[k].update_root(games[k])   # reads game.end: one small host sync per move, as the reference's loop has
+                ended = np.atleast_1d(games[k].end)
+                if ended.any():
+                    episodes += int(ended.sum())
+                    lines += int(np.atleast_1d(games[k].line_clears)[ended].sum())
+                    games[k].reset("ended")
+                    agts[k].update_root(games[k])
         if timed and not args.graph:
             torch.cuda.synchronize()
-            for e in ev:
-                t_tree += e[0].elapsed_time(e[1])
-                t_nn += e[1].elapsed_time(e[2])
-            n_tree += sims
-            n_nn += sims
+            for k in range(NS):
+                for e in ev[k]:
+                    t_tree += e[0].elapsed_time(e[1])
+                    t_nn += e[1].elapsed_time(e[2])
+            n_tree += sims * NS
+            n_nn += sims * NS
+
+    def counters():
+        return {k: sum(S.counter(k) for S in stores) for k in ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL")}
 
     for _ in range(args.warmup):
         one_step(False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    c0 = {k: S.counter(k) for k in ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL")}
+    c0 = counters()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -126,8 +150,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    c1 = {k: S.counter(k) for k in c0}
-    err = int((S.errors() != 0).sum().item())
+    c1 = counters()
+    err = sum(int((S.errors() != 0).sum().item()) for S in stores)
     d = {k: c1[k] - c0[k] for k in c0}
     tot = torch.tensor([elapsed, d["N_EXPAND"], d["N_SIMS"], d["TRACE_SUM"], d["N_EVAL"], episodes, lines, err],
                        dtype=torch.float64, device=dev)
@@ -156,7 +180,7 @@ def main():
                         "Tetris 20x10 app=1 guideline scoring 7-bag; node pool %d/game; Net() random init manual_seed(0)"
                         % (G, sims, args.agent, 1 if args.agent == "ValueSim" else 2, args.max_nodes),
             "games_per_gpu": G, "sims_per_move": sims, "agent": args.agent, "max_nodes": args.max_nodes,
-            "valuenet_backend": args.backend, "graph": bool(args.graph),
+            "valuenet_backend": args.backend, "graph": bool(args.graph), "streams": NS,
         },
         "sims_per_sec": n_sims / elapsed,
         "child_steps_per_sec": 7.0 * n_exp / elapsed,
@@ -165,19 +189,19 @@ def main():
         "episodes_finished": int(episodes),
         "lines_cleared_per_episode": (lines / episodes) if episodes else None,
         "error_games": int(err),
-        "store_gib_per_gpu": S.nbytes() / 2**30,
+        "store_gib_per_gpu": sum(S.nbytes() for S in stores) / 2**30,
     }
     if not args.graph and n_nn:
         nn_ms, tree_ms = t_nn / n_nn, t_tree / n_tree
-        evals_per_launch = n_eval / (args.steps * sims * world)
+        evals_per_launch = n_eval / (args.steps * sims * world * NS)
         flops = FLOP_PER_STATE * evals_per_launch
         a_tf = flops / (nn_ms * 1e-3) / 1e12
         bps = bytes_per_sim(mean_len, 1 if args.agent == "ValueSim" else n_eval / max(n_exp, 1.0))
-        a_gbs = bps * G / (tree_ms * 1e-3) / 1e9
-        nn_roof = {"kernel": "value net forward (tm_valuenet_forward + eval render), per launch of %d states" % (G * K),
+        a_gbs = bps * Gs / (tree_ms * 1e-3) / 1e9
+        nn_roof = {"kernel": "value net forward (tm_valuenet_forward + eval render), per launch of %d states" % (Gs * K),
                    "bound": "mfma", "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                    "frac": a_tf / PEAK_F32_MATRIX_TFLOPS, "traffic": None, "avg_launch_ms": nn_ms}
-        tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % G, "bound": "hbm",
+        tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % Gs, "bound": "hbm",
                      "achieved": a_gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBPS,
                      "traffic": None, "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps}
         out["roofline"] = nn_roof if nn_ms >= tree_ms else tree_roof

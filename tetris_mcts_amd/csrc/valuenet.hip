@@ -228,14 +228,16 @@ __global__ __launch_bounds__(256, 1) void k_vn_conv(const float* __restrict__ P,
             const uint32_t* key = obs_key + ((size_t)(s / eval_slots) * max_nodes + o) * 12;
             uint32_t kw = (lane < 12) ? key[lane] : 0u;
             const uint32_t cells = __shfl((int)kw, 10, 64), endw = __shfl((int)kw, 11, 64);
-            for (int i = lane; i < 200; i += 64) {
-                int r = i / 10, c = i - 10 * r;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {   // uniform trip count: the shuffles below need every lane active
+                const int i = lane + 64 * it, ic = min(i, 199);
+                int r = ic / 10, c = ic - 10 * r;
                 uint32_t w2 = (uint32_t)__shfl((int)kw, r >> 1, 64);
                 float v = (float)((w2 >> (16 * (r & 1) + c)) & 1u);
-                bool pc = ((cells & 0xFF) == (uint32_t)i) | (((cells >> 8) & 0xFF) == (uint32_t)i) |
-                          (((cells >> 16) & 0xFF) == (uint32_t)i) | ((cells >> 24) == (uint32_t)i);
+                bool pc = ((cells & 0xFF) == (uint32_t)ic) | (((cells >> 8) & 0xFF) == (uint32_t)ic) |
+                          (((cells >> 16) & 0xFF) == (uint32_t)ic) | ((cells >> 24) == (uint32_t)ic);
                 if (!(endw & 0xFFu) && pc) v = -1.0f;
-                x0[i] = (o == 0) ? 0.0f : v;
+                if (i < 200) x0[i] = (o == 0) ? 0.0f : v;
             }
         }
         lds_fence();
