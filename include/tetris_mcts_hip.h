@@ -37,7 +37,8 @@ enum {
     TM_GS_ERR, TM_GS_N_EXPAND, TM_GS_N_SIMS, TM_GS_N_GC, TM_GS_RNG_POS, TM_GS_N_NQ_FALLBACK,
     TM_GS_LEAF, TM_GS_LEAF_END, TM_GS_K_EVAL, TM_GS_LEAF_SCORE,
     TM_GS_TRACE_SUM, /* sum of trace lengths over all simulations (for bytes/simulation accounting) */
-    TM_GS_N_EVAL     /* leaf states handed to the evaluator */
+    TM_GS_N_EVAL,    /* leaf states handed to the evaluator */
+    TM_GS_CYC_BACK = 20, TM_GS_CYC_SELECT, TM_GS_CYC_EXPAND, TM_GS_CYC_TAIL  /* shader cycles of the last simulation's phases */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */

@@ -20,11 +20,12 @@ namespace tmcts {
 constexpr int WPB = 4;  // wavefronts (games) per workgroup
 constexpr int NQ_LDS = 2048;  // entries of nq_table mirrored in LDS (child-visit sums are mostly small)
 
+constexpr int TRACE_LDS = 128;   // trace entries buffered in LDS before a coalesced flush
 struct WaveLds {
     uint32_t slots[8][GAME_DW];  // 0..6 successor games, 7 the parent
     uint32_t okeys[7][OBS_DW];
-    uint32_t rng[32];
     uint32_t misc[64];
+    uint4 tbuf[TRACE_LDS];       // (node, obs, score bits, 0) of the walk in progress
 };
 
 struct GP {  // base pointers of one game
@@ -57,6 +58,9 @@ __device__ __forceinline__ GP game_ptrs(const tm_store& S, int g) {
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ uint32_t shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+// wave-uniform source lane: v_readlane_b32 (scalar path, a few cycles) instead of an LDS-crossbar ds_bpermute
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ float rl_f32(float v, int src) { return __uint_as_float(rl_u32(__float_as_uint(v), src)); }
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     uint32_t lo = shfl_u32((uint32_t)v, src), hi = shfl_u32((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
@@ -69,12 +73,10 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
 // glibc rand() (TYPE_3, r[i] = r[i-3] + r[i-31]; core.h:62,76 call the process-global generator, here
 // one stream per game, all lanes of the wave step it redundantly on the LDS copy)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_rand(WaveLds& L, int& pos) {
+__device__ __forceinline__ uint32_t wave_rand(uint32_t& rs, int& pos) {
     int f = pos & 0xFF, b = (pos >> 8) & 0xFF;
-    uint32_t val = L.rng[f] + L.rng[b];
-    wave_sync();
-    L.rng[f] = val;
-    wave_sync();
+    uint32_t val = rl_u32(rs, f) + rl_u32(rs, b);
+    rs = ((int)(threadIdx.x & 63) == f) ? val : rs;
     f += 1;
     if (f >= 31) { f = 0; b += 1; }
     else { b += 1; if (b >= 31) b = 0; }
@@ -105,7 +107,7 @@ __device__ inline void srand_state(uint32_t* r /* 32 words */, int& pos, uint32_
 }
 
 // special.h:26-33, used only beyond the host-built table (counted in TM_GS_N_NQ_FALLBACK)
-__device__ inline float norm_quantile_dev(double t) {
+__device__ __attribute__((noinline)) float norm_quantile_dev(double t) {
     double alpha = 1 - 1 / t;
     return (float)(10 * log(1 - log(-log(alpha) / log(2.0)) / log(22.0)) / log(41.0));
 }
@@ -549,10 +551,10 @@ __device__ inline void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L,
 // the front half: select_trace_obs (core.h:167-224), then expansion and evaluation requests
 // ---------------------------------------------------------------------------------------------------
 __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, const float* nq_lds, int g, int lane) {
-    if (lane < 32) L.rng[lane] = S.rng[(size_t)g * 32 + lane];
+    const long long tc_start = __builtin_readcyclecounter();
+    uint32_t rs = (lane < 32) ? S.rng[(size_t)g * 32 + lane] : 0u;   // glibc rand() state word i in lane i
     int rng_pos = P.gs[TM_GS_RNG_POS];
     const int rng_pos0 = rng_pos;
-    wave_sync();
     int idx = P.gs[TM_GS_ROOT];
     int len = 0;
     uint32_t hdr = 0, self_o = 0;
@@ -562,38 +564,58 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
     // Each level needs the node record and then the statistics of its <=7 unique child observations.  The
     // records of those children are requested together with the statistics (168 dwords = 3 loads per lane), so
     // the record of whichever child gets selected is already in registers: one memory round trip per level.
+    // Nothing is stored to global memory inside the walk (stores share the load counter on gfx9: a store per
+    // level would make every level wait for its acknowledgement); the trace goes through LDS and is flushed
+    // 128 entries at a time with coalesced 16-byte stores.
     int pf_child[3], pf_word[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) { int e = lane + 64 * r; pf_child[r] = e / TM_REC_DW; pf_word[r] = e - pf_child[r] * TM_REC_DW; }
+    const int my_slot = lane < 7 ? lane : 0;
     uint32_t d = (lane < TM_REC_DW) ? P.rec[(size_t)idx * TM_REC_DW + lane] : 0u;
+    int flushed = 0;
+    auto flush_trace = [&](int upto) {   // entries [flushed, upto) from LDS to global, 64 per pass
+        for (int base = flushed; base < upto; base += 64) {
+            int i = base + lane;
+            if (i < upto) reinterpret_cast<uint4*>(P.trace)[i] = L.tbuf[i - flushed];
+        }
+        flushed = upto;
+    };
     for (;;) {
-        hdr = shfl_u32(d, 0);
-        self_o = shfl_u32(d, 1);
-        uint32_t self_sc = shfl_u32(d, 2);
+        hdr = rl_u32(d, 0);
+        self_o = rl_u32(d, 1);
+        uint32_t self_sc = rl_u32(d, 2);
         if (len >= S.max_trace) { overflow = true; break; }
-        if (lane == 0) reinterpret_cast<uint4*>(P.trace)[len] = make_uint4((uint32_t)idx, self_o, self_sc, 0u);
+        if (len - flushed == TRACE_LDS) { wave_sync(); flush_trace(len); wave_sync(); }
+        if (lane == 0) L.tbuf[len - flushed] = make_uint4((uint32_t)idx, self_o, self_sc, 0u);
         len += 1;
         const int nu = (int)(hdr & 7u);
         if (nu == 0) break;
-        const int rep = (int)((hdr >> (3 + 3 * (lane < 7 ? lane : 0))) & 7u);
+        // one round of cross-lane gathers, all sourced from the record itself (hdr is wave-uniform)
+        const int rep = (int)((hdr >> (3 + 3 * my_slot)) & 7u);
         const uint32_t c = shfl_u32(d, 3 + rep), o = shfl_u32(d, 10 + rep);
         const float sc = __uint_as_float(shfl_u32(d, 17 + rep));
-        const bool on = lane < nu;
-        uint4 st = make_uint4(0, 0, 0, 0);
-        if (on) st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
-        uint32_t pre[3];
+        uint32_t pcc[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            uint32_t cc = shfl_u32(c, pf_child[r] < 7 ? pf_child[r] : 0);
-            pre[r] = (pf_child[r] < nu) ? P.rec[(size_t)cc * TM_REC_DW + pf_word[r]] : 0u;
+            int t = pf_child[r] < 7 ? pf_child[r] : 0;
+            int rep_t = (int)((hdr >> (3 + 3 * t)) & 7u);
+            uint32_t cc = shfl_u32(d, 3 + rep_t);
+            pcc[r] = (pf_child[r] < nu) ? cc : 0u;     // slots past nu read node 0 (all zero, always valid)
         }
-        const int visit = (int)st.x;
+        const bool on = lane < nu;
+        const uint32_t osafe = on ? o : 0u;
+        // one round of loads: statistics of the unique child observations + their records (speculative)
+        const uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)osafe * 4);
+        uint32_t pre[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) pre[r] = P.rec[(size_t)pcc[r] * TM_REC_DW + pf_word[r]];
+        const int visit = on ? (int)st.x : 0;
         const uint64_t lowmask = __ballot(on && visit < low);
         int sel;
         if (lowmask) {
             // check_low (core.h:65-77): a uniformly drawn under-visited child, libc rand()
             int m = __popcll(lowmask);
-            uint32_t r = wave_rand(L, rng_pos);
+            uint32_t r = wave_rand(rs, rng_pos);
             int kth = (int)(r % (uint32_t)m);
             uint64_t mm = lowmask;
             for (int t = 0; t < kth; ++t) mm &= mm - 1;
@@ -601,7 +623,8 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
         } else {
             // policy_clt (core.h:83-105): float arithmetic, one rounding per operation
             int n = 0;
-            for (int i = 0; i < 7; ++i) { int vi = (int)shfl_u32((uint32_t)visit, i); n += (i < nu) ? vi : 0; }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { int vi = (int)rl_u32((uint32_t)visit, i); n += (i < nu) ? vi : 0; }
             float coeff;
             if (n < NQ_LDS && n < S.nq_size) coeff = nq_lds[n];
             else if (n < S.nq_size) coeff = S.nq_table[n];
@@ -614,13 +637,14 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
             float prod = coeff * root;
             float q = val + prod;
             sel = 0;
-            float max_q = __uint_as_float(shfl_u32(__float_as_uint(q), 0));
+            float max_q = rl_f32(q, 0);
+#pragma unroll
             for (int i = 1; i < 7; ++i) {
-                float qi = __uint_as_float(shfl_u32(__float_as_uint(q), i));
+                float qi = rl_f32(q, i);
                 if (i < nu && qi > max_q) { max_q = qi; sel = i; }
             }
         }
-        idx = (int)shfl_u32(c, sel);
+        idx = (int)rl_u32(c, sel);
         {   // the selected child's record out of the prefetched block
             int e = sel * TM_REC_DW + (lane < TM_REC_DW ? lane : 0);
             uint32_t v0 = shfl_u32(pre[0], e & 63), v1 = shfl_u32(pre[1], e & 63), v2 = shfl_u32(pre[2], e & 63);
@@ -628,6 +652,9 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
             d = (lane < TM_REC_DW) ? (r == 0 ? v0 : (r == 1 ? v1 : v2)) : 0u;
         }
     }
+    wave_sync();
+    flush_trace(len);
+    const long long tc_sel = __builtin_readcyclecounter();
     const int leaf = idx;
     const int leaf_end = (int)((hdr >> 24) & 1u);
     int k_eval = 0;
@@ -657,7 +684,10 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
     } else {
         if (lane < S.eval_slots) P.eval_obs[lane] = 0;
     }
+    const long long tc_exp = __builtin_readcyclecounter();
     if (lane == 0) {
+        P.gs[TM_GS_CYC_SELECT] = (int)(tc_sel - tc_start);
+        P.gs[TM_GS_CYC_EXPAND] = (int)(tc_exp - tc_sel);
         P.gs[TM_GS_TRACE_LEN] = len;
         P.gs[TM_GS_PENDING] = 1;
         P.gs[TM_GS_LEAF] = leaf;
@@ -669,8 +699,7 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
         if (nq_fallback) P.gs[TM_GS_N_NQ_FALLBACK] += nq_fallback;
     }
     if (rng_pos != rng_pos0) {
-        wave_sync();
-        if (lane < 32) S.rng[(size_t)g * 32 + lane] = L.rng[lane];
+        if (lane < 32) S.rng[(size_t)g * 32 + lane] = rs;
         if (lane == 0) P.gs[TM_GS_RNG_POS] = rng_pos;
     }
 }
@@ -840,10 +869,13 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     if (g >= S.n_games) return;
     GP P = game_ptrs(S, g);
     WaveLds& L = lds[w];
+    const long long t0 = __builtin_readcyclecounter();
     if ((flags & TM_SIM_BACKUP) && P.gs[TM_GS_PENDING]) {
         wave_sim_back(S, P, L, lane);
         __threadfence_block();
     }
+    const long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) P.gs[TM_GS_CYC_BACK] = (int)(t1 - t0);
     if (flags & TM_SIM_FRONT) wave_sim_front(S, P, L, nq_lds, g, lane);
 }
 
