@@ -200,13 +200,52 @@ def gen_valuenet():
     return params
 
 
+def gen_cppagent():
+    """The reference's all-C++ agent (agents/cppmodule/agent.cpp MCTSAgent, compiled in place into oracle/_ref/) on the
+    oracle engine with the hash evaluator: per-move (action, score, lines) for LP and non-LP."""
+    ref_shims.install()
+    from pyTetris import Tetris
+    agent_mod = sys.modules["agents.cppmodule.agent"]
+
+    def ev_lp(obs):
+        a = np.asarray(obs).astype(np.int8)
+        v, var = hash_eval(a.reshape(a.shape[0], 20, 10))
+        return [v.tolist(), var.tolist()]
+
+    def ev_single(obs):
+        a = np.asarray(obs).astype(np.int8)
+        v, var = hash_eval(a.reshape(1, 20, 10))
+        return [float(v[0]), float(var[0])]
+    out = []
+    for lp, sims, max_nodes, seed, moves in ((True, 30, 8000, 31, 200), (False, 40, 8000, 32, 200)):
+        ref_shims.srand(1)
+        agent = agent_mod.MCTSAgent(sims, max_nodes, True, 0.999, False, ev_lp if lp else ev_single, 0, lp)
+        game = Tetris((20, 10), 1, 0, 0, seed)
+        agent.update_root(game)
+        rec = []
+        for _ in range(moves):
+            a = int(agent.play())
+            game.play(a)
+            agent.update_root(game)
+            rec.append([a, int(game.score), int(game.line_clears)])
+            if game.end:
+                game.reset()
+                agent.update_root(game)
+        out.append(dict(lp=lp, sims=sims, max_nodes=max_nodes, seed=seed, moves=rec))
+        print("MCTSAgent LP=%s moves %d final score %d" % (lp, len(rec), rec[-1][1]))
+    with open(os.path.join(OUT, "ref_cppagent.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent"]
     params = None
     if "uct" in which:
         gen_uct()
     if "valuenet" in which:
         params = gen_valuenet()
+    if "cppagent" in which:
+        gen_cppagent()
     if "agents" in which:
         if params is None:
             params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]

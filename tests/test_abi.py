@@ -56,3 +56,16 @@ def test_missing_library_fails_loudly(monkeypatch):
         assert "no CPU path" in str(e)
     else:
         raise AssertionError("expected a loud failure")
+
+
+def test_play_cli_keeps_the_reference_flags():
+    """play.py:46-70 of the reference: every flag, its type and default survive."""
+    import play
+    p = play.build_parser()
+    ref = dict(agent_type=None, app=1, benchmark=False, cycle=0, endless=False, gamma=0.9, gui=False, interactive=False,
+               mcts_const=5.0, mcts_sims=50, mcts_tau=1.0, min_visit=40, ngames=50, online=False, printboard=False,
+               print_board_to_file=False, realtime_status=False, save=False, save_dir='./data/', save_file='data',
+               save_tree=False, tetris_randomizer=0, tetris_scoring=0)
+    d = vars(p.parse_args([]))
+    for k, v in ref.items():
+        assert d[k] == v and type(d[k]) is type(v), k

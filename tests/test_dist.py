@@ -1,0 +1,81 @@
+"""Multi-process path on CPU (gloo, world_size 2): sharding covers the games exactly once and the all-gather of
+variable-length training tuples returns the rank-ordered union on every rank (= the single-process multiset)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tuples(rank):
+    rng = np.random.default_rng(100 + rank)
+    n = [5, 0, 9, 3][rank % 4] + 2 * rank
+    keys = rng.integers(-2**31, 2**31 - 1, size=(n, 12), dtype=np.int64).astype(np.int32)
+    stats = rng.random((n, 4)).astype(np.float32)
+    return torch.from_numpy(keys), torch.from_numpy(stats)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from tetris_mcts_amd import dist as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, s = _tuples(rank)
+    ka, sa = tdist.all_gather_tuples(k, s)
+    q.put((rank, ka.numpy(), sa.numpy(), tdist.shard_range(4099, rank, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_tuples_gloo_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp_k = np.concatenate([_tuples(r)[0].numpy() for r in range(world)])
+    exp_s = np.concatenate([_tuples(r)[1].numpy() for r in range(world)])
+    shards = []
+    for rank, ka, sa, sh in sorted(res, key=lambda t: t[0]):
+        assert np.array_equal(ka, exp_k) and sa.tobytes() == exp_s.tobytes()
+        shards.append(sh)
+    assert shards[0][0] == 0 and shards[0][0] + shards[0][1] == shards[1][0] and shards[1][0] + shards[1][1] == 4099
+
+
+def test_shard_range_partitions():
+    from tetris_mcts_amd.dist import shard_range
+    for n, w in ((4096, 8), (32768, 8), (10, 3), (7, 8)):
+        parts = [shard_range(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+        for a, b in zip(parts, parts[1:]):
+            assert a[0] + a[1] == b[0]
+
+
+def test_render_observations_matches_oracle(oracle):
+    from tetris_mcts_amd.dist import render_observations
+    rng = np.random.default_rng(3)
+    keys, ref = [], []
+    for seed in range(40):
+        g = oracle.Game(seed=seed)
+        for _ in range(int(rng.integers(0, 120))):
+            g.play(int(rng.integers(0, 7)))
+        keys.append(g.packed_obs().view(np.int32).reshape(12))
+        ref.append(g.getState())
+    out = render_observations(torch.from_numpy(np.stack(keys))).numpy().reshape(-1, 20, 10)
+    assert np.array_equal(out, np.stack(ref).astype(np.float32))

@@ -151,3 +151,65 @@ def test_full_size_batch_properties():
     # nodes allocated == pool size - free, and never more than 7 per expansion + the root
     used = (12000 - 1) - gs[:, 2]
     assert (used <= 7 * gs[:, 7] + 1).all() and (used >= gs[:, 7]).all()
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_reference_cpp_agent_golden_runs(golden_dir, idx):
+    """tests/golden/ref_cppagent.json: the reference's all-C++ MCTSAgent (agent.cpp compiled in place)."""
+    with open(os.path.join(golden_dir, "ref_cppagent.json")) as f:
+        r = json.load(f)[idx]
+    game, agent = _make("ValueSimC", 1, r["sims"], r["max_nodes"], r["seed"], evaluator=hash_eval_torch,
+                        leaf_parallel=r["lp"])
+    for i, (act, score, lines) in enumerate(r["moves"]):
+        got = agent.play()
+        assert got == act, (i, got, act)
+        game.play(got)
+        agent.update_root(game)
+        assert (game.score, game.line_clears) == (score, lines), i
+        if game.end:
+            game.reset()
+            agent.update_root(game)
+    assert agent.store.counter("N_GC") >= 1
+
+
+def test_replay_harvest_matches_oracle(oracle):
+    """GC-time replay tuples (ValueSim.store_nodes, ValueSim.py:122-159): same multiset as the oracle's memory."""
+    G, sims, mn = 3, 40, 6000
+    game, agent = _make("ValueSim", G, sims, mn, 21, evaluator=hash_eval_torch, online=True, min_visits_to_store=3,
+                        replay_cap=20000)
+    og = [oracle.Game(seed=21 + g) for g in range(G)]
+    oa = [oracle.Agent(0, max_nodes=mn, online=True, memory_size=100000, min_visits_to_store=3) for _ in range(G)]
+    for g in range(G):
+        oa[g].update_root(og[g])
+    for m in range(120):
+        act = agent.play()
+        for g in range(G):
+            a = oa[g].play(sims)
+            assert a == act[g]
+            og[g].play(a)
+            oa[g].update_root(og[g])
+        game.play(act)
+        agent.update_root(game)
+        ended = game.end
+        if ended.any():
+            game.reset("ended")
+            agent.update_root(game)
+            for g in np.nonzero(ended)[0]:
+                og[g].reset()
+                oa[g].update_root(og[g])
+    assert agent.store.counter("N_GC") == sum(o.n_gc for o in oa) >= 1
+    cnt = agent.store.t["replay_count"].cpu().numpy()
+    for g in range(G):
+        st_o, val_o, var_o, vis_o = oa[g].memory()
+        assert cnt[g] == len(val_o)
+        keys = agent.store.t["replay_obs"][g, :cnt[g]].cpu().numpy().view(np.uint32)
+        stat = agent.store.t["replay_stat"][g, :cnt[g]].cpu().numpy()
+        # render the packed observations with the oracle and compare tuple by tuple (same ascending order)
+        for i in range(cnt[g]):
+            o = np.zeros(1, oracle.OBS_DTYPE)
+            o.view(np.uint32)[:] = keys[i]
+            out = np.zeros(200, np.int8)
+            oracle.lib().orc_obs_render(oracle.ptr(o), oracle.ptr(out))
+            assert np.array_equal(out, st_o[i]), (g, i)
+        assert stat[:, 0].tobytes() == val_o.tobytes() and stat[:, 1].tobytes() == var_o.tobytes()
+        assert np.array_equal(stat[:, 2], vis_o)

@@ -56,3 +56,24 @@ def test_store_nodes_emits_replay_tuples(oracle):
     assert len(st) > 0 and (vis >= 3).all()
     assert set(np.unique(st)) <= {-1, 0, 1}
     a.close()
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_agent_oracle_replays_reference_cpp_agent(oracle, golden_dir, idx):
+    """tests/golden/ref_cppagent.json: agents/cppmodule/agent.cpp MCTSAgent (compiled in place), LP and non-LP."""
+    with open(os.path.join(golden_dir, "ref_cppagent.json")) as f:
+        r = json.load(f)[idx]
+    g = oracle.Game(seed=r["seed"])
+    a = oracle.Agent(2 if r["lp"] else 3, max_nodes=r["max_nodes"])
+    a.update_root(g)
+    for i, (act, score, lines) in enumerate(r["moves"]):
+        got = a.play(r["sims"])
+        assert got == act, (i, got, act)
+        g.play(got)
+        a.update_root(g)
+        assert (g.score, g.line_clears) == (score, lines), i
+        if g.end:
+            g.reset()
+            a.update_root(g)
+    assert a.n_gc >= 1
+    a.close()

@@ -1,0 +1,69 @@
+"""Multi-GPU: one process per GPU, games sharded by index, one exchange step.
+
+The reference has no collective at all (replicas write separate files, cycle.sh:69-73).  Games are independent
+(every agent owns its tree, agents/agent.py:58-88), so rank r simply owns games [r*G/P, (r+1)*G/P) with private
+pools and RNG streams.  The only exchange is the all-gather of the (state, TD-target) training tuples that GC
+harvests (ValueSim.store_nodes, ValueSim.py:122-159), so every rank can train the same replica on the union.
+Backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous, balanced shard: (start, count) of rank's games out of n_total."""
+    base, rem = divmod(int(n_total), int(world))
+    start = rank * base + min(rank, rem)
+    return start, base + (1 if rank < rem else 0)
+
+
+def all_gather_tuples(obs_keys, stats, group=None):
+    """All-gather variable-length training tuples.
+
+    obs_keys: int32 [n, 12] packed observations (ENGINE_SPEC.md section 7); stats: float32 [n, 4] = value, variance,
+    visit, 0.  Returns (obs_keys_all, stats_all) = the concatenation over ranks in rank order (identical on every
+    rank).  One count all-gather (8 B/rank) + one padded payload all-gather (64 B/tuple).
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return obs_keys, stats
+    world = dist.get_world_size(group)
+    dev = obs_keys.device
+    n = torch.tensor([obs_keys.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    if m == 0:
+        return obs_keys, stats
+    # one fused payload: 12 key words + 4 stat words (bit-cast) per tuple
+    pay = torch.zeros(m, 16, dtype=torch.int32, device=dev)
+    pay[:obs_keys.shape[0], :12] = obs_keys.to(torch.int32)
+    pay[:obs_keys.shape[0], 12:] = stats.contiguous().view(torch.int32)
+    out = [torch.empty_like(pay) for _ in range(world)]
+    dist.all_gather(out, pay, group=group)
+    allp = torch.cat([out[r][:counts[r]] for r in range(world)], dim=0)
+    return allp[:, :12].contiguous(), allp[:, 12:].contiguous().view(torch.float32)
+
+
+def render_observations(obs_keys):
+    """Packed observations int32 [n,12] -> float32 [n,1,20,10] network inputs (0 empty, 1 locked, -1 falling piece);
+    the layout of the reference's replay memory (ValueSim.py:24-29).  Plain tensor ops (off the hot path)."""
+    k = obs_keys.to(torch.int64) & 0xFFFFFFFF
+    n = k.shape[0]
+    rows = torch.stack([(k[:, r // 2] >> (16 * (r % 2))) & 0xFFFF for r in range(20)], dim=1)      # [n,20]
+    cols = torch.arange(10, device=k.device)
+    board = ((rows[:, :, None] >> cols[None, None, :]) & 1).to(torch.float32)                       # [n,20,10]
+    cells = torch.stack([(k[:, 10] >> (8 * i)) & 0xFF for i in range(4)], dim=1)                    # [n,4]
+    ended = (k[:, 11] & 0xFF) != 0
+    flat = board.reshape(n, 200)
+    idx = cells.clamp(max=199)
+    piece = torch.zeros_like(flat).scatter_(1, idx, 1.0) * (~ended)[:, None].to(torch.float32)
+    piece = piece * (cells.min(dim=1).values < 200)[:, None].to(torch.float32)
+    flat = torch.where(piece > 0, torch.full_like(flat, -1.0), flat)
+    return flat.reshape(n, 1, 20, 10)
+
+
+def training_arrays(obs_keys, stats):
+    """(states [n,1,20,10], values [n,1], variance [n,1], weights [n,1]) as ValueSim.memory holds them."""
+    return render_observations(obs_keys), stats[:, 0:1].clone(), stats[:, 1:2].clone(), stats[:, 2:3].clone()
