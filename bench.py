@@ -23,6 +23,24 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (den
 PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
 
 
+def pmc_traffic(kernels, fetch_scale=1.0):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json; counters can
+    not be read from inside this process, and the guide asks for separate passes).  FETCH_SIZE + WRITE_SIZE are
+    KiB per dispatch; fetch_scale = 2 for kernels whose reads are wide coalesced streams (gfx950 under-report)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        k = json.load(f)["kernels"]
+    tot = 0.0
+    for name in kernels:
+        e = k.get(name)
+        if not e:
+            return None
+        tot += 1024.0 * (fetch_scale * e["FETCH_SIZE_KB_last50_mean"] + e["WRITE_SIZE_KB_last50_mean"])
+    return tot
+
+
 def bytes_per_sim(mean_trace_len, k_eval):
     """SURVEY.md 8(d) algorithmic bytes per simulation (packed game 64 B, packed observation 64 B, U = 7)."""
     return 204.0 * mean_trace_len - 144.0 + 1296.0 + 1000.0 * k_eval
@@ -202,10 +220,17 @@ def main():
         a_gbs = bps * Gs / (tree_ms * 1e-3) / 1e9
         nn_roof = {"kernel": "value net forward (tm_valuenet_forward + eval render), per launch of %d states" % (Gs * K),
                    "bound": "mfma", "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                   "frac": a_tf / PEAK_F32_MATRIX_TFLOPS, "traffic": None, "avg_launch_ms": nn_ms}
+                   "frac": a_tf / PEAK_F32_MATRIX_TFLOPS,
+                   "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1", "tmcts_vn::k_vn_fcout"], 2.0)
+                   if args.backend == "hip" else None,
+                   "traffic_note": "bytes/launch, FETCH_SIZE x2 (wide streams) + WRITE_SIZE from profiles/r01_pmc_traffic.json",
+                   "avg_launch_ms": nn_ms}
         tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % Gs, "bound": "hbm",
                      "achieved": a_gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBPS,
-                     "traffic": None, "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps}
+                     "traffic": pmc_traffic(["tmcts::k_sim_step"]),
+                     "traffic_note": "bytes/launch of 4096 games at mean trace length ~20 (move 1), FETCH_SIZE + WRITE_SIZE "
+                                     "from profiles/r01_pmc_traffic.json (narrow scattered accesses: no gfx950 correction)",
+                     "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps}
         out["roofline"] = nn_roof if nn_ms >= tree_ms else tree_roof
         out["roofline_other"] = tree_roof if nn_ms >= tree_ms else nn_roof
     if world == 1 and not args.no_cpu_baseline:
