@@ -25,6 +25,17 @@ class Agent:
     def get_prob(self):
         raise NotImplementedError('get_action not implemented')
 
+    def get_value_and_variance(self, node=None):
+        """Root observation's (value, variance) (agents/agent.py:195-204); only node=None (the root) is supported."""
+        if node is not None:
+            raise NotImplementedError("only the root is addressable on the device store")
+        s = self.store
+        g = torch.arange(self.n_games, device=s.device)
+        root = s.t["gs"][:, st.GS["ROOT"]].long()
+        o = s.t["node_rec"][g, root, 1].long()
+        vv = s.t["obs_stat"][g, o, 1:3].view(torch.float32).cpu().numpy()
+        return (vv[0, 0], vv[0, 1]) if self.n_games == 1 else (vv[:, 0], vv[:, 1])
+
     def update_root(self, game):
         raise NotImplementedError('update_root not implemented')
 
@@ -129,6 +140,17 @@ class TreeAgent(Agent):
         s = self.get_stats().reshape(-1, 3, 7)
         p = s[:, 0] / s[:, 0].sum(axis=1, keepdims=True)
         return p[0] if self.n_games == 1 else p
+
+    def get_value_and_variance(self, node=None):
+        """Root observation's (value, variance) (agents/agent.py:195-204); only node=None (the root) is supported."""
+        if node is not None:
+            raise NotImplementedError("only the root is addressable on the device store")
+        s = self.store
+        g = torch.arange(self.n_games, device=s.device)
+        root = s.t["gs"][:, st.GS["ROOT"]].long()
+        o = s.t["node_rec"][g, root, 1].long()
+        vv = s.t["obs_stat"][g, o, 1:3].view(torch.float32).cpu().numpy()
+        return (vv[0, 0], vv[0, 1]) if self.n_games == 1 else (vv[:, 0], vv[:, 1])
 
     def update_root(self, game):
         if self.store is None:

@@ -20,7 +20,7 @@ namespace tmcts {
 constexpr int WPB = 4;  // wavefronts (games) per workgroup
 constexpr int NQ_LDS = 2048;  // entries of nq_table mirrored in LDS (child-visit sums are mostly small)
 
-constexpr int TRACE_LDS = 128;   // trace entries buffered in LDS before a coalesced flush
+constexpr int TRACE_LDS = 64;   // trace entries buffered in LDS before a coalesced flush
 struct WaveLds {
     uint32_t slots[8][GAME_DW];  // 0..6 successor games, 7 the parent
     uint32_t okeys[7][OBS_DW];
@@ -333,23 +333,38 @@ __device__ inline bool wave_expand(const tm_store& S, const GP& P, WaveLds& L, i
         L.misc[32 + lane] = sbits;
     }
     wave_sync();
-    // get_unique_child_obs (core.h:126-142), evaluated once here because its inputs never change
-    if (lane == 0) {
-        int nu = 0;
-        for (int a = 0; a < 7; ++a) {
-            uint32_t c = L.misc[16 + a];
-            if (c == 0) continue;
-            uint32_t ob = L.misc[24 + a];
-            int j = -1;
-            for (int t = 0; t < nu; ++t)
-                if (L.misc[48 + t] == ob) { j = t; break; }
-            if (j < 0) { L.misc[40 + nu] = (uint32_t)a; L.misc[48 + nu] = ob; nu += 1; }
-            else if (__uint_as_float(L.misc[32 + a]) > __uint_as_float(L.misc[32 + L.misc[40 + j]])) L.misc[40 + j] = (uint32_t)a;
+    // get_unique_child_obs (core.h:126-142), evaluated once here because its inputs never change.  Lane a owns
+    // action a: "first" = earliest action with the same observation; the first lane of each group then scans the
+    // group in action order keeping the strictly-greater score (the reference's replacement rule) and the groups
+    // are compacted in first-seen order.
+    {
+        const bool act7 = lane < 7;
+        const uint32_t my_c = act7 ? (uint32_t)idx : 0u, my_o = act7 ? (uint32_t)o : 0u;
+        const float my_s = __uint_as_float(sbits);
+        int first = lane;
+        int best = lane;
+        float best_s = my_s;
+        bool seen_first = false;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const uint32_t cb = rl_u32(my_c, b), ob = rl_u32(my_o, b);
+            const float sb = rl_f32(my_s, b);
+            const bool same = act7 && cb != 0 && my_c != 0 && ob == my_o;
+            if (same && !seen_first) { first = b; seen_first = true; best = b; best_s = sb; }
+            else if (same && sb > best_s) { best = b; best_s = sb; }
         }
+        // only the group's first lane holds the full scan (it starts at itself); others started later or earlier,
+        // so recompute "best" from the first lane's point of view: lanes with first == lane are the leaders.
+        const bool leader = act7 && my_c != 0 && first == lane;
+        const uint64_t lead_mask = __ballot(leader);
+        const int nu = __popcll(lead_mask);
+        const int slot = __popcll(lead_mask & ((1ull << lane) - 1ull));
         uint32_t hdr = (uint32_t)nu | (1u << 25);
-        for (int t = 0; t < nu; ++t) hdr |= L.misc[40 + t] << (3 + 3 * t);
-        L.misc[56] = hdr;
-        P.rec[(size_t)leaf * TM_REC_DW] = hdr;
+        // every leader contributes its representative action at its slot
+        uint32_t contrib = leader ? ((uint32_t)best << (3 + 3 * slot)) : 0u;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) hdr |= rl_u32(contrib, b);
+        if (lane == 0) { L.misc[56] = hdr; P.rec[(size_t)leaf * TM_REC_DW] = hdr; }
     }
     wave_sync();
     hdr_out = L.misc[56];
@@ -416,7 +431,7 @@ __device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lan
         double x = 0;
         float xf = 0;
         for (int j = 0; j < cnt; ++j) {
-            float sj = __uint_as_float(shfl_u32(e.z, j));
+            float sj = rl_f32(__uint_as_float(e.z), j);   // wave-uniform source lane
             if (float_carry) {
                 Vf = Vf - sj;
                 if (lane == j) xf = Vf;
@@ -522,9 +537,9 @@ __device__ inline void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L,
             }
             double vt = 0, vart = 0;
             for (int i = 0; i < k; ++i) {
-                float vi = __uint_as_float(shfl_u32(__float_as_uint(cval), i));
-                float ri = __uint_as_float(shfl_u32(__float_as_uint(cvar), i));
-                float si = __uint_as_float(shfl_u32(__float_as_uint(cs), i));
+                float vi = rl_f32(cval, i);
+                float ri = rl_f32(cvar, i);
+                float si = rl_f32(cs, i);
                 double gv = S.gamma * (double)vi;
                 vt = vt + ((double)si + gv);
                 vart = vart + (double)ri;
