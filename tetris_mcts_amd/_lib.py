@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtetris_mcts_hip.so")
+LIB_PATH = os.environ.get("TETRIS_MCTS_LIB", os.path.join(HERE, "libtetris_mcts_hip.so"))
 
 vp, i32, f64 = C.c_void_p, C.c_int32, C.c_double
 

@@ -18,7 +18,11 @@
 namespace tmcts {
 
 constexpr int WPB = 4;  // wavefronts (games) per workgroup
-constexpr int NQ_LDS = 2048;  // entries of nq_table mirrored in LDS (child-visit sums are mostly small)
+#ifdef TM_SMALL_LDS
+constexpr int NQ_LDS = 512;
+#else
+constexpr int NQ_LDS = 2048;
+#endif  // entries of nq_table mirrored in LDS (child-visit sums are mostly small)
 
 constexpr int TRACE_LDS = 64;   // trace entries buffered in LDS before a coalesced flush
 struct WaveLds {

@@ -103,6 +103,9 @@ __global__ void k_fc_out(const float* __restrict__ h, int hstride, const float* 
 //   T4[(s/4)*64 + l][s%4]
 // ===================================================================================================
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef TM_SCHED_REGION_QUADS
+#define TM_SCHED_REGION_QUADS 6
+#endif
 constexpr int PREP_W2 = 0, PREP_W3 = 9216, PREP_W1 = 18432, PREP_TOTAL = 18432 + 458752;
 constexpr int A1CS = 145;   // conv1-output channel stride in LDS (18*8 = 144, +1 against bank conflicts)
 constexpr int A2CS = 97;    // conv2-output channel stride in LDS (16*6 = 96, +1)
@@ -173,16 +176,21 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, const in
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        // close the scheduling region here: the group solver's cost grows steeply with the number of groups in a
-        // region (36 quads in one region took minutes to compile), and nothing needs to move across quads
-        __builtin_amdgcn_sched_barrier(0);
+        // Close the scheduling region every few quads: the group solver's cost grows steeply with the number of
+        // groups in one region (all 36 quads in one region take minutes to compile).
+        if (q % TM_SCHED_REGION_QUADS == TM_SCHED_REGION_QUADS - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // Input: either int8 states [n][200], or (states == nullptr) evaluation requests of the tree engine:
 // request s refers to packed observation eval_obs[s] of game s / eval_slots (ENGINE_SPEC.md section 7), rendered
 // here on the fly (0 empty, 1 locked, -1 falling piece; request 0 = unused slot = empty board).
-__global__ __launch_bounds__(256, 1) void k_vn_conv(const float* __restrict__ P, const float* __restrict__ prep,
+#ifdef TM_CONV_CAP256
+#define TM_CONV_WAVES 2
+#else
+#define TM_CONV_WAVES 1
+#endif
+__global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __restrict__ P, const float* __restrict__ prep,
                                                     const int8_t* __restrict__ states, const uint32_t* __restrict__ obs_key,
                                                     const int32_t* __restrict__ eval_obs, int eval_slots, int max_nodes,
                                                     int n, float* __restrict__ a3out, int a3stride) {
@@ -223,6 +231,19 @@ __global__ __launch_bounds__(256, 1) void k_vn_conv(const float* __restrict__ P,
     const float4* W3 = reinterpret_cast<const float4*>(prep + PREP_W3) + lane;
 
     for (int s = blockIdx.x * 4 + w; s < n; s += gridDim.x * 4) {
+#ifdef TM_CONV_CAP256
+        // variant: weight streams re-read per state (an opaque zero offset defeats hoisting) so the kernel fits in
+        // 256 registers and other wavefronts can share its SIMDs
+        int zoff = 0;
+        asm volatile("" : "+s"(zoff));
+        const float4* W2s = W2 + zoff;
+        const float4* W3s = W3 + zoff;
+#else
+        const float4* W2s = W2;
+        const float4* W3s = W3;
+#endif
+        // unused evaluation slots (request 0) are skipped: their outputs are never read
+        if (!states && eval_obs[s] == 0) continue;
         // ---- input ----
         if (states) {
             for (int i = lane; i < 200; i += 64) x0[i] = (float)states[(size_t)s * 200 + i];
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void k_vn_conv(const float* __restrict__ P,
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = bias2[r];
-            conv_mfma<3, A1CS>(a1, boff2, W2, acc);
+            conv_mfma<3, A1CS>(a1, boff2, W2s, acc);
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -297,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void k_vn_conv(const float* __restrict__ P,
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = bias3[r];
-            conv_mfma<2, A2CS>(a2, boff3, W3, acc);
+            conv_mfma<2, A2CS>(a2, boff3, W3s, acc);
             float* dst = a3out + (size_t)s * a3stride;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -316,50 +337,76 @@ __global__ __launch_bounds__(256, 1) void k_vn_conv(const float* __restrict__ P,
     }
 }
 
-// fc1 (1792 -> 256) + ReLU.  A wave owns one 32 (hidden) x 32 (states) accumulator; the four waves of a workgroup
-// take four hidden tiles of the same 32 states, so the activation rows they all read stay in the CU's L1.
-// Both operands come straight from global memory (no LDS staging, no barriers): lane (state j, half h) needs
-// a3[j][2s+h] for step s, i.e. every second element of its state's row; it loads the row 8 floats at a time
-// (two dwordx4: the two halves of a lane pair read the same 32 bytes, which the memory pipeline merges) and the
-// weight quads from the prepared T4 stream.  Loads run two 4-step groups ahead of the MFMAs.
+// fc1 (1792 -> 256) + ReLU: a workgroup owns 32 states x 128 hidden units (one 32x32 accumulator per wave).
+constexpr int FC_KC = 64, FC_PITCH = FC_KC + 1;
 __global__ __launch_bounds__(256) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
                                                 float* __restrict__ hout, int hstride) {
+    __shared__ float bt[2][32 * FC_PITCH];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
     const int s0 = blockIdx.x * 32;
     const int ht = blockIdx.y * 4 + w;   // hidden tile 0..7
     const float4* W = reinterpret_cast<const float4*>(prep + PREP_W1) + (size_t)ht * 224 * 64 + lane;
-    const int sj = min(s0 + l31, n - 1);   // rows past n replicate the last state; their results are discarded
-    const float4* X = reinterpret_cast<const float4*>(a3 + (size_t)sj * a3stride);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = P[OFF_F1B + 32 * ht + (r & 3) + 8 * (r >> 2) + 4 * half];
-    constexpr int NQ = A3 / 8;   // 224 groups of 4 MFMA steps (8 k each)
-    constexpr int DEPTH = 4;     // groups in flight (NQ is a multiple of it: static register indexing)
-    float4 wq[DEPTH], xa[DEPTH], xb[DEPTH];
+    // staging: 32 rows x 64 floats per chunk = 512 float4, two per thread
+    const int row0 = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;   // rows row0 and row0+16
+    float4 st0, st1;
+    auto gload = [&](int chunk) {
+        int sa = s0 + row0, sb = s0 + row0 + 16;
+        st0 = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4) : make_float4(0, 0, 0, 0);
+        st1 = (sb < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sb * a3stride + chunk * FC_KC + c4) : make_float4(0, 0, 0, 0);
+    };
+    auto lstore = [&](int buf) {
+        float* d0 = &bt[buf][row0 * FC_PITCH + c4];
+        d0[0] = st0.x; d0[1] = st0.y; d0[2] = st0.z; d0[3] = st0.w;
+        float* d1 = &bt[buf][(row0 + 16) * FC_PITCH + c4];
+        d1[0] = st1.x; d1[1] = st1.y; d1[2] = st1.z; d1[3] = st1.w;
+    };
+    constexpr int NCH = A3 / FC_KC;   // 28 chunks of 64 k = 32 MFMA steps = 8 weight quads
+    float4 wbuf[2][8];
+    auto wload = [&](int chunk, int buf) {
 #pragma unroll
-    for (int q = 0; q < DEPTH - 1; ++q) { wq[q] = W[q * 64]; xa[q] = X[2 * q]; xb[q] = X[2 * q + 1]; }
-#pragma unroll 4
-    for (int q = 0; q < NQ; ++q) {
-        const int qn = q + DEPTH - 1;
-        if (qn < NQ) { wq[qn % DEPTH] = W[qn * 64]; xa[qn % DEPTH] = X[2 * qn]; xb[qn % DEPTH] = X[2 * qn + 1]; }
-        const float4 w4 = wq[q % DEPTH], x0 = xa[q % DEPTH], x1 = xb[q % DEPTH];
-        // k = 8q + 2r + half  ->  x0.{x|y}, x0.{z|w}, x1.{x|y}, x1.{z|w}
-        const float b0 = half ? x0.y : x0.x, b1 = half ? x0.w : x0.z, b2 = half ? x1.y : x1.x, b3 = half ? x1.w : x1.z;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, b1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, b2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, b3, acc, 0, 0, 0);
+        for (int q = 0; q < 8; ++q) wbuf[buf][q] = W[((size_t)chunk * 8 + q) * 64];
+    };
+    gload(0);
+    wload(0, 0);
+    lstore(0);
+    __syncthreads();
+#pragma unroll 2
+    for (int c = 0; c < NCH; ++c) {
+        // requests for the next chunk (activations -> registers, weights -> the other register buffer) go out first
+        if (c + 1 < NCH) { gload(c + 1); wload(c + 1, (c + 1) & 1); }
+        const float* b = &bt[c & 1][l31 * FC_PITCH + half];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 w4 = wbuf[c & 1][q];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, b[2 * (4 * q + 0)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, b[2 * (4 * q + 1)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, b[2 * (4 * q + 2)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, b[2 * (4 * q + 3)], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);   // the 10 global loads lead the chunk
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (c + 1 < NCH) lstore((c + 1) & 1);
+        __syncthreads();
     }
-    if (s0 + l31 < n) {
+    const int sj = s0 + l31;
+    if (sj < n) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int i = 32 * ht + (r & 3) + 8 * (r >> 2) + 4 * half;
             float v = acc[r];
-            hout[(size_t)(s0 + l31) * hstride + i] = v > 0.0f ? v : 0.0f;
+            hout[(size_t)sj * hstride + i] = v > 0.0f ? v : 0.0f;
         }
     }
 }
+
 
 // fc_out (256 -> 2) + sigmoid + affine for 32 states per workgroup: hidden rows staged in LDS, one lane per
 // (state, output) walks the 256-term fma chain in order.
@@ -442,7 +489,7 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
                        eval_slots, max_nodes, n, scratch, SS);
     hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(256), 0, stream, P, prepared, scratch, SS, n,
                        scratch + A3, SS);
-    hipLaunchKernelGGL(k_vn_fcout, dim3((n + 31) / 32), dim3(64), 0, stream, scratch + A3, SS, P, v, var, n);
+    hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, v, var, n);
     return (int)hipGetLastError();
 }
 
