@@ -131,7 +131,7 @@ int tm_core_backup_trace_obs_lp(int n_trees, int n_nodes, const int32_t *trace, 
                                 int max_trace, int32_t *visit, float *value, float *variance, const int32_t *n_to_o,
                                 const float *score, const uint8_t *end, const int32_t *_child /* [B][7] */,
                                 const int32_t *_obs, const int32_t *k, const float *_value, const float *_variance,
-                                double gamma, void *stream);
+                                double gamma, int mixture, int averaged, void *stream);
 int tm_core_get_unique_child_obs(int n_trees, int n_nodes, const int32_t *index, const int32_t *child,
                                  const float *score, const int32_t *n_to_o, int32_t *c_nodes /* [B][7] */,
                                  int32_t *c_obs, int32_t *count, void *stream);

@@ -105,6 +105,35 @@ def gen_uct():
     print("ref_uct.npz:", len(cases), "cases")
 
 
+def gen_uct_mixture():
+    """backup_trace_obs_LP with mixture / non-averaged flags (core.h:262-301,303-381) through the reference's core.cpp."""
+    ref_shims.install()
+    core = sys.modules["agents.cppmodule.core"]
+    rng = np.random.default_rng(77)
+    flat = {}
+    for ci in range(8):
+        child, n_to_o, score, visit, value, variance = random_dag(rng, 300, 150, low_visits=False)
+        ref_shims.srand(1)
+        v, val, var = visit.copy(), value.copy(), variance.copy()
+        for rep in range(10):
+            # a trace that ends in an EXPANDED node, so the LP child list is non-empty
+            root = int(rng.integers(1, 40))
+            t = np.asarray(core.select_trace_obs(root, child, v, val, var, score, n_to_o, 1), np.int32)
+            if len(t) > 1:
+                t = t[:-1].copy()
+            leaf = int(t[-1])
+            cn, co = core.get_unique_child_obs(leaf, child, score, n_to_o)
+            k = len(cn)
+            end = np.zeros(300, bool)
+            _v = (rng.random(k) * 60).astype(np.float32)
+            _var = (rng.random(k) * 400).astype(np.float32)
+            mixture, averaged = bool(rep & 1), bool(rep & 2)
+            core.backup_trace_obs_LP(t, v, val, var, n_to_o, score, end, list(cn), list(co), _v, _var, 0.98, mixture, averaged)
+        flat["m%d_visit1" % ci], flat["m%d_value1" % ci], flat["m%d_variance1" % ci] = v, val, var
+    np.savez_compressed(os.path.join(OUT, "ref_uct_mixture.npz"), **flat)
+    print("ref_uct_mixture.npz: 8 cases")
+
+
 def play_ref(name, sims, max_nodes, seed, max_moves, evaluator):
     ref_shims.install()
     from pyTetris import Tetris
@@ -238,7 +267,7 @@ def gen_cppagent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -246,6 +275,8 @@ if __name__ == "__main__":
         params = gen_valuenet()
     if "cppagent" in which:
         gen_cppagent()
+    if "mixture" in which:
+        gen_uct_mixture()
     if "agents" in which:
         if params is None:
             params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]

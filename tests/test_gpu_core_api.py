@@ -92,7 +92,7 @@ def test_core_api_matches_reference_golden(golden_dir):
                 _r[:k] = (rng.random(k) * 400).astype(np.float32)
                 _lib.check(L.tm_core_backup_trace_obs_lp(1, N, _p(trace), _p(tl), 512, _p(t_visit), _p(t_value), _p(t_var),
                                                          _p(t_n2o), _p(t_score), _p(d(end)), _p(cn), _p(co), _p(cnt),
-                                                         _p(d(_v)), _p(d(_r)), C.c_double(0.999), _stream()), "backup_lp")
+                                                         _p(d(_v)), _p(d(_r)), C.c_double(0.999), 0, 1, _stream()), "backup_lp")
         root = int(rng.integers(1, 60))
         mark = torch.zeros(N, dtype=torch.uint8, device=dev)
         queue = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -103,3 +103,64 @@ def test_core_api_matches_reference_golden(golden_dir):
         assert t_visit.cpu().numpy()[:no].tobytes() == gold[name + "_visit1"].tobytes(), ci
         assert t_value.cpu().numpy()[:no].tobytes() == gold[name + "_value1"].tobytes(), ci
         assert t_var.cpu().numpy()[:no].tobytes() == gold[name + "_variance1"].tobytes(), ci
+
+
+def test_core_api_mixture_backup(golden_dir):
+    """backup_trace_obs_LP with mixture / non-averaged flags vs the reference's own outputs (ref_uct_mixture.npz)."""
+    import torch
+    from tetris_mcts_amd import _lib
+    from tetris_mcts_amd.store import norm_quantile_table, _p, _stream
+    from oracle import binding as B
+    L = _lib.lib()
+    gold = np.load(os.path.join(golden_dir, "ref_uct_mixture.npz"))
+    dev = torch.device("cuda")
+    nq = norm_quantile_table(1 << 16, dev)
+    keep = []
+
+    def d(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        keep.append(t)
+        return t
+    rng = np.random.default_rng(77)
+    N = 300
+    for ci in range(8):
+        child, n_to_o, score, visit, value, variance = random_dag(rng, N, 150, low_visits=False)
+        padn = lambda a: np.concatenate([a, np.zeros(N - len(a), a.dtype)])  # noqa: E731
+        t_child, t_n2o, t_score = d(child), d(n_to_o), d(score)
+        t_visit, t_value, t_var = d(padn(visit)), d(padn(value)), d(padn(variance))
+        o = np.zeros(36, np.int32)
+        B.lib().orc_srand(B.ptr(o), 1)
+        st = np.zeros(32, np.uint32)
+        st[:31] = o[:31].view(np.uint32)
+        st[31] = int(o[34]) | (int(o[35]) << 8)
+        t_rng = d(st.view(np.int32))
+        trace = torch.zeros(512, dtype=torch.int32, device=dev)
+        tl = torch.zeros(1, dtype=torch.int32, device=dev)
+        cn = torch.zeros(7, dtype=torch.int32, device=dev)
+        co = torch.zeros(7, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        for rep in range(10):
+            root = int(rng.integers(1, 40))
+            _lib.check(L.tm_core_select_trace_obs(1, N, _p(d(np.array([root], np.int32))), _p(t_child), _p(t_visit),
+                                                  _p(t_value), _p(t_var), _p(t_score), _p(t_n2o), 1, _p(t_rng), _p(nq),
+                                                  nq.numel(), _p(trace), _p(tl), 512, _stream()), "select")
+            n = int(tl.item())
+            if n > 1:
+                n -= 1
+                tl.fill_(n)
+            leaf = d(np.array([int(trace[n - 1].item())], np.int32))
+            _lib.check(L.tm_core_get_unique_child_obs(1, N, _p(leaf), _p(t_child), _p(t_score), _p(t_n2o), _p(cn), _p(co),
+                                                      _p(cnt), _stream()), "unique")
+            k = int(cnt.item())
+            _v = np.zeros(7, np.float32)
+            _r = np.zeros(7, np.float32)
+            _v[:k] = (rng.random(k) * 60).astype(np.float32)
+            _r[:k] = (rng.random(k) * 400).astype(np.float32)
+            _lib.check(L.tm_core_backup_trace_obs_lp(1, N, _p(trace), _p(tl), 512, _p(t_visit), _p(t_value), _p(t_var),
+                                                     _p(t_n2o), _p(t_score), _p(d(np.zeros(N, np.uint8))), _p(cn), _p(co),
+                                                     _p(cnt), _p(d(_v)), _p(d(_r)), C.c_double(0.98), rep & 1,
+                                                     1 if rep & 2 else 0, _stream()), "backup_lp")
+        no = len(visit)
+        assert t_visit.cpu().numpy()[:no].tobytes() == gold["m%d_visit1" % ci].tobytes(), ci
+        assert t_value.cpu().numpy()[:no].tobytes() == gold["m%d_value1" % ci].tobytes(), ci
+        assert t_var.cpu().numpy()[:no].tobytes() == gold["m%d_variance1" % ci].tobytes(), ci

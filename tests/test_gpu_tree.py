@@ -213,3 +213,31 @@ def test_replay_harvest_matches_oracle(oracle):
             assert np.array_equal(out, st_o[i]), (g, i)
         assert stat[:, 0].tobytes() == val_o.tobytes() and stat[:, 1].tobytes() == var_o.tobytes()
         assert np.array_equal(stat[:, 2], vis_o)
+
+
+def test_online_training_loop(tmp_path, monkeypatch):
+    """ValueSim online: GC harvests (state, TD target) tuples on the device, train_nodes fits the net on them
+    (Yogi + Gaussian KL, ValueSim.py:161-185, model.py:176-249) and the search keeps running with the new weights."""
+    import torch
+    from tetris_mcts_amd import model as M
+    monkeypatch.setattr(M, "EXP_PATH", str(tmp_path) + "/")
+    model = M.Model_VV(backend="hip", seed=0)
+    game, agent = _make("ValueSim", 16, 40, 5000, 5, model=model, online=True, min_visits_to_store=3, replay_cap=8192)
+    before = model.flat_params().clone()
+    for m in range(90):
+        act = agent.play()
+        game.play(act)
+        agent.update_root(game)
+        if game.end.any():
+            game.reset("ended")
+            agent.update_root(game)
+    assert agent.store.counter("N_GC") >= 1
+    n_tuples = int(agent.store.t["replay_count"].sum().item())
+    assert n_tuples > 50
+    res = agent.train_nodes(iters_per_val=20, batch_size=256, max_iters=60)
+    assert res is not None and res["iters"] >= 20
+    after = model.flat_params()
+    assert not torch.equal(before, after)
+    assert int(agent.store.t["replay_count"].sum().item()) == 0
+    act = agent.play()            # the search runs on with the updated network (prepared weight streams refreshed)
+    assert act.shape == (16,) and (agent.store.errors() == 0).all()

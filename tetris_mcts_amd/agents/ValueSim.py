@@ -15,9 +15,13 @@ class ValueSim(TreeAgent):
                  max_nodes=100000, model=None, evaluator=None, **kwargs):
         kwargs.pop("min_visit", None)  # play.py:89 forwards it; the reference ValueSim ignores it too
         benchmark = kwargs.get("benchmark", False)
+        kwargs.setdefault("replay_cap", 4096 if (online and not benchmark) else 0)
         super().__init__(max_nodes=max_nodes, gamma=gamma, online=(online and not benchmark),
                          min_visits_to_store=min_visits_to_store, **kwargs)
         self.online = online
+        self.n_trains = 0
+        self._memory = None       # (packed observations, stats) carried over between trainings
+        kwargs_cap = memory_size
         self.memory_size = memory_size
         self.memory_growth_rate = memory_growth_rate
         self.min_visits_to_store = min_visits_to_store
@@ -41,3 +45,38 @@ class ValueSim(TreeAgent):
             self.model.inference_requests(self.store)   # observations rendered inside the conv kernel
         else:
             super().evaluate_requests()
+
+    # ---- online training (ValueSim.py:161-185): the reference trains inside remove_nodes(), in the middle of a
+    # simulation of its single game; the batched engine harvests tuples at GC time on the device and trains between
+    # moves, on the union over all games and all ranks (tetris_mcts_amd/dist.py) ----
+    def train_nodes(self, dump_data=False, **train_kwargs):
+        import torch
+        from .. import dist as tdist
+        from sys import stderr
+        if not self.online or self.evaluator is not None:
+            return None
+        s = self.store
+        keys, stats = s.replay()
+        s.t["replay_count"].zero_()
+        if self._memory is not None:
+            keys = torch.cat([self._memory[0], keys])
+            stats = torch.cat([self._memory[1], stats])
+        keys, stats = keys[:self.memory_size], stats[:self.memory_size]
+        keys_all, stats_all = tdist.all_gather_tuples(keys.view(torch.int32), stats)
+        d_size = keys_all.shape[0]
+        m_size = min(self.n_trains * self.memory_growth_rate, self.memory_size)
+        if d_size < max(m_size, 1):
+            print("Not enough training data ({} < {}), collecting more data.".format(d_size, m_size), file=stderr, flush=True)
+            self._memory = (keys, stats)
+            return None
+        print("Enough training data ({} >= {}), proceed to training.".format(d_size, m_size), file=stderr, flush=True)
+        data = list(tdist.training_arrays(keys_all, stats_all))
+        self.n_trains += 1
+        opts = dict(iters_per_val=100, batch_size=1024, max_iters=50000)
+        opts.update(train_kwargs)
+        res = self.model.train_data(data, **opts)
+        self.model.training(False)
+        self._memory = None
+        self._graph = None    # weights changed: a captured graph would still be valid (same buffers), prepared streams are refreshed lazily
+        print("Training complete.", file=stderr, flush=True)
+        return res

@@ -115,6 +115,31 @@ __device__ inline void backup_one(const int32_t* tr, int len, int32_t* visit, fl
     }
 }
 
+// core.h:262-301
+__device__ inline void backup_one_mixture(const int32_t* tr, int len, int32_t* visit, float* value, float* variance,
+                                          const int32_t* n_to_o, const float* score, double _value, double _variance,
+                                          double gamma) {
+    for (int i = len - 1; i >= 0; --i) {
+        int idx = tr[i];
+        _value = _value - (double)score[idx];
+        int o = n_to_o[idx];
+        visit[o] += 1;
+        double a = _value * _value;
+        double b = (double)(value[o] * value[o]);   // float*float, rounded to float first
+        double v_sq_diff = a - b;
+        double v_tmp = (double)value[o];
+        double delta = (_value - (double)value[o]) / (double)visit[o];
+        value[o] = (float)((double)value[o] + delta);
+        double var_diff = _variance - (double)variance[o];
+        double t1 = (var_diff + v_sq_diff) / (double)visit[o];
+        double t2 = delta * (v_tmp + (double)value[o]);
+        variance[o] = (float)(((double)variance[o] + t1) - t2);
+        double t = gamma * _value;
+        _value = t + (double)score[idx];
+        _variance = _variance * (gamma * gamma);
+    }
+}
+
 __global__ void k_backup(int B, int N, const int32_t* trace, const int32_t* trace_len, int max_trace, int32_t* visit,
                          float* value, float* variance, const int32_t* n_to_o, const float* score, const double* _value,
                          const double* _variance, double gamma) {
@@ -128,13 +153,17 @@ __global__ void k_backup(int B, int N, const int32_t* trace, const int32_t* trac
 __global__ void k_backup_lp(int B, int N, const int32_t* trace, const int32_t* trace_len, int max_trace, int32_t* visit,
                             float* value, float* variance, const int32_t* n_to_o, const float* score, const uint8_t* end,
                             const int32_t* _child, const int32_t* _obs, const int32_t* kk, const float* _value,
-                            const float* _variance, double gamma) {
+                            const float* _variance, double gamma, int mixture, int averaged) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     size_t off = (size_t)b * N;
     visit += off; value += off; variance += off; n_to_o += off; score += off; end += off;
     const int32_t* tr = trace + (size_t)b * max_trace;
     int len = trace_len[b], k = kk[b];
+    auto backup = [&](double v0, double var0) {
+        if (mixture) backup_one_mixture(tr, len, visit, value, variance, n_to_o, score, v0, var0, gamma);
+        else backup_one(tr, len, visit, value, variance, n_to_o, score, v0, var0, gamma);
+    };
     if (k > 0) {
         double v_tmp = 0, var_tmp = 0;
         for (int i = 0; i < k; ++i) {
@@ -144,15 +173,23 @@ __global__ void k_backup_lp(int B, int N, const int32_t* trace, const int32_t* t
                 if (end[c]) { value[o] = 0; variance[o] = 0; }
                 else { value[o] = _value[b * 7 + i]; variance[o] = _variance[b * 7 + i]; }
             }
-            double gv = gamma * (double)value[o];
-            v_tmp = v_tmp + ((double)score[c] + gv);
-            var_tmp = var_tmp + (double)variance[o];
+            if (averaged) {
+                double gv = gamma * (double)value[o];
+                v_tmp = v_tmp + ((double)score[c] + gv);
+                var_tmp = var_tmp + (double)variance[o];
+            } else {
+                double gs = gamma * (double)score[c];
+                double gg = gamma * gamma;
+                backup((double)value[o] + gs, gg * (double)variance[o]);
+            }
         }
-        v_tmp = v_tmp / (double)k;
-        var_tmp = var_tmp * (gamma * gamma / (double)k);
-        backup_one(tr, len, visit, value, variance, n_to_o, score, v_tmp, var_tmp, gamma);
+        if (averaged) {
+            v_tmp = v_tmp / (double)k;
+            var_tmp = var_tmp * (gamma * gamma / (double)k);
+            backup(v_tmp, var_tmp);
+        }
     } else {
-        backup_one(tr, len, visit, value, variance, n_to_o, score, (double)score[tr[len - 1]], 0, gamma);
+        backup((double)score[tr[len - 1]], 0);
     }
 }
 
@@ -209,9 +246,10 @@ int tm_core_backup_trace_obs(int B, int N, const int32_t* trace, const int32_t* 
 int tm_core_backup_trace_obs_lp(int B, int N, const int32_t* trace, const int32_t* trace_len, int max_trace,
                                 int32_t* visit, float* value, float* variance, const int32_t* n_to_o, const float* score,
                                 const uint8_t* end, const int32_t* _child, const int32_t* _obs, const int32_t* k,
-                                const float* _value, const float* _variance, double gamma, void* stream) {
+                                const float* _value, const float* _variance, double gamma, int mixture, int averaged,
+                                void* stream) {
     hipLaunchKernelGGL(k_backup_lp, GRID(B), B, N, trace, trace_len, max_trace, visit, value, variance, n_to_o, score,
-                       end, _child, _obs, k, _value, _variance, gamma);
+                       end, _child, _obs, k, _value, _variance, gamma, mixture, averaged);
     return (int)hipGetLastError();
 }
 int tm_core_get_unique_child_obs(int B, int N, const int32_t* index, const int32_t* child, const float* score,

@@ -60,19 +60,56 @@ class Model_VV:
     def training(self, mode=True):
         self.model.train(mode)
 
+    # ---- training side (model/model.py:97-249, model_vv.py:125-134,227-231) ----
+    def _optimizer(self):
+        if getattr(self, "optimizer", None) is None:
+            from .train import Yogi
+            params = [p for p in self.model.parameters() if p.requires_grad]
+            self.optimizer = Yogi(params, lr=1e-3, eps=1e-3, weight_decay=1e-3)
+        return self.optimizer
+
+    def train_data(self, data, **kwargs):
+        """data: [states [n,1,20,10], values [n,1], variances [n,1], weights [n,1]] (numpy or tensors)."""
+        from . import train as T
+        dev = self.device
+        data = [torch.as_tensor(d, dtype=torch.float32, device=dev) for d in data]
+        with torch.no_grad():
+            self.model.out_ubound.copy_(torch.stack([data[1].max(), data[2].max()]))   # model_vv.py:228-229
+        best = {}
+
+        def save():
+            best["model"] = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+            self.save(verbose=False)
+
+        def load():
+            self.model.load_state_dict(best["model"])
+        res = T.train_data(self.model, self._optimizer(), data, save=save, load=load, **kwargs)
+        self.model.eval()
+        self._flat = None
+        self._prepared = None
+        return res
+
     def load(self, filename=EXP_PATH + "model_checkpoint"):
         if os.path.isfile(filename):
             print("Loading model...", flush=True)
             ck = torch.load(filename, map_location=self.device)
             self.model.load_state_dict(ck["model_state_dict"])
+            if ck.get("optimizer_state_dict"):
+                try:
+                    self._optimizer().load_state_dict(ck["optimizer_state_dict"])
+                except (ValueError, KeyError):
+                    pass   # a checkpoint written by a different optimiser layout: keep fresh optimiser state
         else:
             print("Checkpoint not found, using default model", flush=True)
         self._flat = None
         self._prepared = None
 
-    def save(self, filename=EXP_PATH + "model_checkpoint"):
+    def save(self, filename=EXP_PATH + "model_checkpoint", verbose=True):
+        if verbose:
+            print("Saving model...", flush=True)
         os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
-        torch.save({"model_state_dict": self.model.state_dict(), "optimizer_state_dict": {}}, filename)
+        opt = self.optimizer.state_dict() if getattr(self, "optimizer", None) is not None else {}
+        torch.save({"model_state_dict": self.model.state_dict(), "optimizer_state_dict": opt}, filename)
 
     def set_flat_params(self, flat):
         """flat: 478342 floats in PARAM_ORDER (tests/golden/ref_valuenet.npz 'params')."""

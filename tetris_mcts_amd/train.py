@@ -1,0 +1,156 @@
+"""Online TD training of the value net — the reference's learning half, as plain PyTorch on
+the GPU (plumbing, not a hot kernel):
+
+  * Yogi optimiser                      model/yogi.py:39-90   (lr 1e-3, eps 1e-3, weight decay 1e-3: model_vv.py:132)
+  * Gaussian KL / likelihood loss       model/model_vv.py:94-101,136-150 (variance clipped at 0.1, optional weights)
+  * Model.train_data                    model/model.py:176-249 (weights / mean, last 10 % validation, random minibatches
+                                        with replacement, validation every `iters_per_val`, early stopping with patience,
+                                        best-checkpoint reload)
+  * Model_VV.train_data                 model/model_vv.py:227-231 (output upper bounds = data maxima)
+  * checkpoint format                   model/model.py:143-174 ({'model_state_dict', 'optimizer_state_dict'})
+"""
+import math
+import os
+from sys import stderr
+
+import torch
+from torch.optim.optimizer import Optimizer
+
+variance_bound = 1e-1
+
+
+class Yogi(Optimizer):
+    """Yogi (Zaheer et al. 2018) with the reference's conventions: v0 = g0^2 (before weight decay), coupled weight
+    decay added to the gradient, bias-corrected step  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)."""
+
+    def __init__(self, params, lr=1e-2, betas=(0.9, 0.999), eps=1e-3, weight_decay=0.0):
+        if lr <= 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("invalid Yogi hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = g * g
+                st["step"] += 1
+                t = st["step"]
+                if group["weight_decay"] != 0:
+                    g = g + group["weight_decay"] * p
+                m, v = st["exp_avg"], st["exp_avg_sq"]
+                m.mul_(b1).add_(g, alpha=1 - b1)
+                g2 = g * g
+                v.sub_((1 - b2) * torch.sign(v - g2) * g2)
+                denom = v.sqrt() / math.sqrt(1 - b2 ** t) + group["eps"]
+                p.sub_((group["lr"] / (1 - b1 ** t)) * m / denom)
+        return loss
+
+
+def gaussian_kl(var_pred, mean_pred, var, mean):
+    """KL( N(mean,var) || N(mean_pred,var_pred) ) up to the factor 1/2 the reference also drops."""
+    return var_pred.log() + ((mean - mean_pred) ** 2 + var) / var_pred - var.log() - 1.0
+
+
+def batch_loss(net, batch, weighted, variance_clip=variance_bound):
+    state, value, variance, weight = batch
+    variance = variance.clamp(min=variance_clip)
+    out = net(state)
+    v, var = out[:, 0:1], out[:, 1:2]
+    per = gaussian_kl(var, v, variance, value)
+    if weighted:
+        per = weight * per
+    return per.mean(), per.std(unbiased=False)
+
+
+@torch.no_grad()
+def validation_loss(net, data, weighted, chunk=1024):
+    """Weighted combination over chunks (model.py:49-84): chunk weight = sum of sample weights (or the count)."""
+    tot_w, acc, acc2 = 0.0, 0.0, 0.0
+    for c in range(0, data[0].shape[0], chunk):
+        b = [d[c:c + chunk] for d in data]
+        mean, std = batch_loss(net, b, weighted)
+        w = float(b[3].sum()) if weighted else float(b[0].shape[0])
+        mean, std = float(mean), float(std)
+        if math.isnan(std):
+            std = 0.0
+        tot_w += w
+        acc += w * mean
+        acc2 += w * (std * std + mean * mean)
+    mean = acc / tot_w
+    return mean, math.sqrt(max(acc2 / tot_w - mean * mean, 0.0))
+
+
+def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validation_fraction=0.1,
+               sample_replacement=True, weighted=True, early_stopping=True, early_stopping_patience=10,
+               early_stopping_threshold=1.0, shuffle=False, max_iters=100000, grad_clip=0.0, save=None, load=None,
+               generator=None, log=True):
+    """data = [states f32 [n,1,20,10], values [n,1], variances [n,1], weights [n,1]] (device tensors).
+    save() / load() persist and restore the best weights (the reference goes through its checkpoint file)."""
+    n = data[0].shape[0]
+    n_val = int(n * validation_fraction)
+    data = list(data)
+    data[3] = data[3] / data[3].mean()
+    if shuffle:
+        perm = torch.randperm(n, device=data[0].device, generator=generator)
+        data = [d[perm] for d in data]
+    train = [d[:n - n_val] for d in data] if n_val else data
+    val = [d[n - n_val:] for d in data] if n_val else None
+    if log:
+        print("Training data size: {}    Validation data size: {}".format(n - n_val, n_val), file=stderr, flush=True)
+    fails, best = 0, float("inf")
+    loss_avg = 0.0
+    iters_done = 0
+    net.train()
+    for it in range(max_iters):
+        if sample_replacement:
+            idx = torch.randint(0, n - n_val, (batch_size,), device=data[0].device, generator=generator)
+        else:
+            idx = torch.randperm(n - n_val, device=data[0].device, generator=generator)[:batch_size]
+        optimizer.zero_grad(set_to_none=True)
+        loss, _ = batch_loss(net, [d[idx] for d in train], weighted)
+        loss.backward()
+        if grad_clip > 0:
+            torch.nn.utils.clip_grad_norm_(net.parameters(), grad_clip)
+        optimizer.step()
+        loss_avg += float(loss.detach())
+        iters_done = it + 1
+        if (it + 1) % iters_per_val == 0 and val is not None:
+            net.eval()
+            vmean, vstd = validation_loss(net, val, weighted)
+            net.train()
+            vstd /= max(n_val, 1) ** 0.5
+            mark = ""
+            if early_stopping:
+                if vmean - best < vstd * early_stopping_threshold:
+                    fails = 0
+                    if vmean < best:
+                        mark = "*"
+                        best = vmean
+                        if save:
+                            save()
+                else:
+                    fails += 1
+            if log:
+                print("Iteration:{:7d}  training loss:{:6.4f}  validation loss:{:6.4f}±{:6.4f}    {}".format(
+                    it + 1, loss_avg / iters_per_val, vmean, vstd, mark), file=stderr, flush=True)
+            loss_avg = 0.0
+            if early_stopping and fails >= early_stopping_patience:
+                break
+    if early_stopping and load and best < float("inf"):
+        load()
+    elif save:
+        save()
+    net.eval()
+    return dict(iters=iters_done, best_validation=best)
