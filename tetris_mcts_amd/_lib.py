@@ -59,6 +59,9 @@ def lib():
             raise RuntimeError(
                 "tetris_mcts_amd: %s is missing. This package has no CPU path; build the HIP library first:\n"
                 "    python -c 'import __graft_entry__ as g; g.build()'" % LIB_PATH)
+        # PyTorch ships its own libamdhip64; it must be the HIP runtime of this process (device memory, streams and
+        # torch.distributed all go through it), so it is loaded first and our library binds to the same copy.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, args in SYMBOLS.items():
             f = getattr(L, name)
