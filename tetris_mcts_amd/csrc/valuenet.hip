@@ -91,6 +91,8 @@ __global__ void k_fc_out(const float* __restrict__ h, int hstride, const float* 
     if (j == 0) v[s] = o; else var[s] = o;
 }
 
+}  // namespace tmcts_vn
+namespace tmcts_vn {
 
 // ===================================================================================================
 // MFMA path.  v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32]; lane l supplies A[i=l&31][k=l>>5] and
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
 }
 
 // fc1 (1792 -> 256) + ReLU: a workgroup owns 32 states x 128 hidden units (one 32x32 accumulator per wave).
-constexpr int FC_KC = 64, FC_PITCH = FC_KC + 1;
+constexpr int FC_KC = 128, FC_PITCH = FC_KC + 1;
 __global__ __launch_bounds__(256) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
                                                 float* __restrict__ hout, int hstride) {
@@ -350,25 +352,30 @@ __global__ __launch_bounds__(256) void k_vn_fc1(const float* __restrict__ P, con
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = P[OFF_F1B + 32 * ht + (r & 3) + 8 * (r >> 2) + 4 * half];
-    // staging: 32 rows x 64 floats per chunk = 512 float4, two per thread
-    const int row0 = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;   // rows row0 and row0+16
-    float4 st0, st1;
+    // staging: 32 rows x 128 floats per chunk = 1024 float4, four per thread (rows row0 + 8 i)
+    const int row0 = threadIdx.x >> 5, c4 = (threadIdx.x & 31) * 4;
+    float4 st[4];
     auto gload = [&](int chunk) {
-        int sa = s0 + row0, sb = s0 + row0 + 16;
-        st0 = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4) : make_float4(0, 0, 0, 0);
-        st1 = (sb < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sb * a3stride + chunk * FC_KC + c4) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int sa = s0 + row0 + 8 * i;
+            st[i] = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4)
+                             : make_float4(0, 0, 0, 0);
+        }
     };
     auto lstore = [&](int buf) {
-        float* d0 = &bt[buf][row0 * FC_PITCH + c4];
-        d0[0] = st0.x; d0[1] = st0.y; d0[2] = st0.z; d0[3] = st0.w;
-        float* d1 = &bt[buf][(row0 + 16) * FC_PITCH + c4];
-        d1[0] = st1.x; d1[1] = st1.y; d1[2] = st1.z; d1[3] = st1.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* d = &bt[buf][(row0 + 8 * i) * FC_PITCH + c4];
+            d[0] = st[i].x; d[1] = st[i].y; d[2] = st[i].z; d[3] = st[i].w;
+        }
     };
-    constexpr int NCH = A3 / FC_KC;   // 28 chunks of 64 k = 32 MFMA steps = 8 weight quads
-    float4 wbuf[2][8];
+    constexpr int NCH = A3 / FC_KC;   // 14 chunks of 128 k = 64 MFMA steps = 16 weight quads
+    constexpr int QPC = FC_KC / 8;
+    float4 wbuf[2][QPC];
     auto wload = [&](int chunk, int buf) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) wbuf[buf][q] = W[((size_t)chunk * 8 + q) * 64];
+        for (int q = 0; q < QPC; ++q) wbuf[buf][q] = W[((size_t)chunk * QPC + q) * 64];
     };
     gload(0);
     wload(0, 0);
@@ -380,18 +387,12 @@ __global__ __launch_bounds__(256) void k_vn_fc1(const float* __restrict__ P, con
         if (c + 1 < NCH) { gload(c + 1); wload(c + 1, (c + 1) & 1); }
         const float* b = &bt[c & 1][l31 * FC_PITCH + half];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < QPC; ++q) {
             const float4 w4 = wbuf[c & 1][q];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, b[2 * (4 * q + 0)], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, b[2 * (4 * q + 1)], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, b[2 * (4 * q + 2)], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, b[2 * (4 * q + 3)], acc, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);   // the 10 global loads lead the chunk
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         if (c + 1 < NCH) lstore((c + 1) & 1);
         __syncthreads();
