@@ -50,6 +50,7 @@ enum {
 #define TM_KIND_VALUESIM_LP 1  /* agents/ValueSimLP.py:44-70    : evaluate the leaf's unique children, core.h:303-381 */
 #define TM_KIND_CPPAGENT_LP 2  /* agent.cpp:420-436,517-566     : float carry, end_obs[o], no gamma^2       */
 #define TM_KIND_CPPAGENT 3     /* agent.cpp:437-446,496-513     : float carry, single leaf                 */
+#define TM_KIND_VANILLA 4      /* agents/Vanilla.py:42-64       : random rollout to the end of the game (CPython MT19937 randint), variance 1e3 */
 
 typedef struct tm_store {
     /* sizes */
@@ -93,6 +94,7 @@ typedef struct tm_store {
     uint32_t *replay_obs; /* [G][replay_cap][12] */
     float *replay_stat;   /* [G][replay_cap][4] value, variance, visit, 0 */
     int32_t *replay_count;/* [G] */
+    uint32_t *mt_state;   /* [G][625] CPython random state per game (624 words + index), TM_KIND_VANILLA rollouts (Vanilla.py:4,52) */
 } tm_store;
 
 /* pools, free lists, tables, rng (seed 1), control blocks.  Everything else must be zero-filled by the caller. */

@@ -54,6 +54,9 @@ def lib():
         for name in ("n_sims", "n_expand", "n_gc", "n_eval_states", "trace_len_sum"):
             f = getattr(L, "orc_agent_" + name)
             f.restype, f.argtypes = C.c_long, [vp]
+        L.orc_agent_set_mt.argtypes = [vp, vp]
+        L.orc_agent_n_rollout_steps.restype, L.orc_agent_n_rollout_steps.argtypes = C.c_long, [vp]
+        L.orc_mt_randint7_test.argtypes = [vp]
         L.orc_game_init.argtypes = [vp, i32, i32, i32, u32]
         L.orc_game_play.argtypes = [vp, i32, i32, i32, i32, vp]
         L.orc_game_reset.argtypes = [vp, i32, i32, i32, vp]
@@ -126,7 +129,7 @@ class Game:
 
 
 class Agent:
-    """Oracle tree agent. kind: 0 ValueSim, 1 ValueSimLP, 2 all-C++ agent LP, 3 all-C++ agent single."""
+    """Oracle tree agent. kind: 0 ValueSim, 1 ValueSimLP, 2 all-C++ agent LP, 3 all-C++ agent single, 4 Vanilla."""
 
     def __init__(self, kind, max_nodes=100000, app=1, scoring=0, randomizer=0, gamma=0.999, low=1, benchmark=False,
                  online=False, min_visits_to_store=None, memory_size=0, evaluator="hash", params=None):
@@ -152,6 +155,12 @@ class Agent:
         self.max_nodes = max_nodes
         self.h = L.orc_agent_new(max_nodes, app, scoring, randomizer, kind, gamma, low, int(benchmark), int(online),
                                  min_visits_to_store, memory_size, fn, ctx)
+
+    def set_python_random_state(self, state):
+        """state = random.getstate() (or random.Random(seed).getstate()): the rollout RNG of Vanilla (Vanilla.py:4,52)."""
+        st = np.asarray(state[1], dtype=np.uint64).astype(np.uint32)
+        assert st.size == 625
+        self.L.orc_agent_set_mt(self.h, ptr(st))
 
     def update_root(self, game):
         self.L.orc_agent_update_root(self.h, ptr(game.g))
@@ -186,7 +195,7 @@ class Agent:
 
     def __getattr__(self, name):
         if name in ("root", "episode", "error", "n_avail", "n_obs_avail", "memory_index", "n_sims", "n_expand",
-                    "n_gc", "n_eval_states", "trace_len_sum"):
+                    "n_gc", "n_eval_states", "trace_len_sum", "n_rollout_steps"):
             return getattr(self.L, "orc_agent_" + name)(self.h)
         raise AttributeError(name)
 

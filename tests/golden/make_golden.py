@@ -105,6 +105,34 @@ def gen_uct():
     print("ref_uct.npz:", len(cases), "cases")
 
 
+def gen_vanilla():
+    """The reference's Vanilla agent (agents/Vanilla.py, random rollouts with random.randint) - BASELINE configs[0]."""
+    import random
+    ref_shims.install()
+    from pyTetris import Tetris
+    out = []
+    for sims, max_nodes, seed, rseed, moves in ((100, 60000, 41, 0, 40), (30, 4000, 42, 7, 120)):
+        ref_shims.srand(1)
+        random.seed(rseed)
+        agent = ref_shims.make_agent("Vanilla", sims, max_nodes=max_nodes)
+        game = Tetris((20, 10), 1, 0, 0, seed)
+        agent.update_root(game)
+        rec = []
+        for _ in range(moves):
+            a = int(agent.play())
+            stats = agent.get_stats()
+            game.play(a)
+            agent.update_root(game)
+            rec.append([a, int(game.score), int(game.line_clears), stats.astype("<f4").tobytes().hex()])
+            if game.end:
+                game.reset()
+                agent.update_root(game)
+        out.append(dict(sims=sims, max_nodes=max_nodes, seed=seed, random_seed=rseed, moves=rec))
+        print("Vanilla sims %d moves %d final score %d" % (sims, len(rec), rec[-1][1]))
+    with open(os.path.join(OUT, "ref_vanilla.json"), "w") as f:
+        json.dump(out, f)
+
+
 def gen_uct_mixture():
     """backup_trace_obs_LP with mixture / non-averaged flags (core.h:262-301,303-381) through the reference's core.cpp."""
     ref_shims.install()
@@ -267,7 +295,7 @@ def gen_cppagent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -277,6 +305,8 @@ if __name__ == "__main__":
         gen_cppagent()
     if "mixture" in which:
         gen_uct_mixture()
+    if "vanilla" in which:
+        gen_vanilla()
     if "agents" in which:
         if params is None:
             params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]

@@ -241,3 +241,60 @@ def test_online_training_loop(tmp_path, monkeypatch):
     assert int(agent.store.t["replay_count"].sum().item()) == 0
     act = agent.play()            # the search runs on with the updated network (prepared weight streams refreshed)
     assert act.shape == (16,) and (agent.store.errors() == 0).all()
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_reference_vanilla_golden_runs(golden_dir, idx):
+    """tests/golden/ref_vanilla.json: the reference's own Vanilla agent (BASELINE configs[0]: 100 sims/move, rollouts)."""
+    from tetris_mcts_amd import agents
+    from tetris_mcts_amd.pyTetris import Tetris
+    with open(os.path.join(golden_dir, "ref_vanilla.json")) as f:
+        r = json.load(f)[idx]
+    game = Tetris((20, 10), 1, 0, 0, seed=r["seed"], n_games=1)
+    agent = agents.Vanilla(sims=r["sims"], env=Tetris, env_args=game.env_args, n_games=1, max_nodes=r["max_nodes"],
+                           random_seed=r["random_seed"])
+    agent.update_root(game)
+    for i, (act, score, lines, stats_hex) in enumerate(r["moves"]):
+        got = agent.play()
+        assert got == act, (i, got, act)
+        assert agent.get_stats().astype("<f4").tobytes().hex() == stats_hex, i
+        game.play(got)
+        agent.update_root(game)
+        assert (game.score, game.line_clears) == (score, lines), i
+        if game.end:
+            game.reset()
+            agent.update_root(game)
+
+
+def test_vanilla_batch_vs_oracle(oracle):
+    import random
+    from tetris_mcts_amd import agents
+    from tetris_mcts_amd.pyTetris import Tetris
+    G, sims, mn = 6, 30, 6000
+    game = Tetris((20, 10), 1, 0, 0, seed=50, n_games=G)
+    agent = agents.Vanilla(sims=sims, env=Tetris, env_args=game.env_args, n_games=G, max_nodes=mn, random_seed=9)
+    agent.update_root(game)
+    og = [oracle.Game(seed=50 + g) for g in range(G)]
+    oa = [oracle.Agent(4, max_nodes=mn, gamma=0.99, low=5) for _ in range(G)]
+    for g in range(G):
+        oa[g].set_python_random_state(random.Random(9 + g).getstate())
+        oa[g].update_root(og[g])
+    for m in range(80):
+        act = agent.play()
+        stats = agent.get_stats()
+        for g in range(G):
+            a = oa[g].play(sims)
+            assert a == act[g], (m, g)
+            assert oa[g].stats().tobytes() == stats[g].tobytes(), (m, g)
+            og[g].play(a)
+            oa[g].update_root(og[g])
+        game.play(act)
+        agent.update_root(game)
+        ended = game.end
+        if ended.any():
+            game.reset("ended")
+            agent.update_root(game)
+            for g in np.nonzero(ended)[0]:
+                og[g].reset()
+                oa[g].update_root(og[g])
+    assert agent.store.counter("N_GC") == sum(o.n_gc for o in oa)

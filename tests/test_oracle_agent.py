@@ -77,3 +77,35 @@ def test_agent_oracle_replays_reference_cpp_agent(oracle, golden_dir, idx):
             a.update_root(g)
     assert a.n_gc >= 1
     a.close()
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_agent_oracle_replays_reference_vanilla(oracle, golden_dir, idx):
+    """tests/golden/ref_vanilla.json: agents/Vanilla.py (random rollouts via random.randint) - BASELINE configs[0]."""
+    import random
+    with open(os.path.join(golden_dir, "ref_vanilla.json")) as f:
+        r = json.load(f)[idx]
+    g = oracle.Game(seed=r["seed"])
+    a = oracle.Agent(4, max_nodes=r["max_nodes"], gamma=0.99, low=5)
+    a.set_python_random_state(random.Random(r["random_seed"]).getstate())
+    a.update_root(g)
+    for i, (act, score, lines, stats_hex) in enumerate(r["moves"]):
+        got = a.play(r["sims"])
+        assert got == act, (i, got, act)
+        assert a.stats().astype("<f4").tobytes().hex() == stats_hex, i
+        g.play(got)
+        a.update_root(g)
+        assert (g.score, g.line_clears) == (score, lines), i
+        if g.end:
+            g.reset()
+            a.update_root(g)
+    a.close()
+
+
+def test_mt19937_randint_matches_cpython(oracle):
+    import random
+    for seed in (0, 5, 123456789):
+        r = random.Random(seed)
+        st = np.asarray(r.getstate()[1], dtype=np.uint64).astype(np.uint32)
+        got = [oracle.lib().orc_mt_randint7_test(oracle.ptr(st)) for _ in range(2000)]
+        assert got == [r.randint(0, 6) for _ in range(2000)]

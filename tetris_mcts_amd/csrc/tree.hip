@@ -31,6 +31,30 @@ struct WaveLds {
     uint32_t misc[64];
     uint4 tbuf[TRACE_LDS];       // (node, obs, score bits, 0) of the walk in progress
 };
+struct MtLds { uint32_t mt[624]; uint32_t idx; uint32_t pad[3]; };   // CPython random state (TM_KIND_VANILLA)
+
+// CPython's genrand_uint32 + random.randint(0, 6) (= _randbelow_with_getrandbits(7): 3 bits, rejection), one lane
+__device__ inline uint32_t mt_next(MtLds& m) {
+    if (m.idx >= 624) {
+        for (int kk = 0; kk < 624; ++kk) {
+            uint32_t y = (m.mt[kk] & 0x80000000u) | (m.mt[(kk + 1) % 624] & 0x7fffffffu);
+            m.mt[kk] = m.mt[(kk + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        m.idx = 0;
+    }
+    uint32_t y = m.mt[m.idx];
+    m.idx += 1;
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+__device__ inline int mt_randint7(MtLds& m) {
+    uint32_t r = mt_next(m) >> 29;
+    while (r >= 7) r = mt_next(m) >> 29;
+    return (int)r;
+}
 
 struct GP {  // base pointers of one game
     uint32_t *rec, *game, *stat, *okey;
@@ -512,7 +536,10 @@ __device__ inline void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L,
     int c_obs[1];
     int n_extra = 0;
     bool seq = false;
-    if (kind == TM_KIND_VALUESIM) {
+    if (kind == TM_KIND_VANILLA) {
+        v0 = (double)leaf_score;   // the rollout's final score (or the terminal leaf's own), Vanilla.py:54,59
+        var0 = leaf_end ? 0.0 : 1e3;
+    } else if (kind == TM_KIND_VALUESIM) {
         v0 = (double)leaf_score;   // Python int score + np.float32 v under numpy 1.17 = float64
         if (!leaf_end) { v0 = v0 + (double)P.eval_v[0]; var0 = (double)P.eval_var[0]; }
     } else if (kind == TM_KIND_CPPAGENT) {
@@ -569,7 +596,7 @@ __device__ inline void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L,
 // ---------------------------------------------------------------------------------------------------
 // the front half: select_trace_obs (core.h:167-224), then expansion and evaluation requests
 // ---------------------------------------------------------------------------------------------------
-__device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, const float* nq_lds, int g, int lane) {
+__device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, const float* nq_lds, int g, int lane) {
     const long long tc_start = __builtin_readcyclecounter();
     uint32_t rs = (lane < 32) ? S.rng[(size_t)g * 32 + lane] : 0u;   // glibc rand() state word i in lane i
     int rng_pos = P.gs[TM_GS_RNG_POS];
@@ -680,10 +707,31 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
     int leaf_score = (int)P.game[(size_t)leaf * GAME_DW + 14];
     if (overflow) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_TRACE); }
     const int kind = S.kind;
+    if (kind == TM_KIND_VANILLA && !leaf_end && !overflow) {
+        // Vanilla.py:47-55: play a copy of the leaf to the end with uniformly random actions, value = final score
+        uint32_t* ms = S.mt_state + (size_t)g * 625;
+        for (int i = lane; i < 625; i += 64) { if (i < 624) M->mt[i] = ms[i]; else M->idx = ms[i]; }
+        if (lane < GAME_DW) L.slots[7][lane] = P.game[(size_t)leaf * GAME_DW + lane];
+        wave_sync();
+        if (lane == 0) {
+            EngCfg cfg{S.app, S.scoring, S.randomizer};
+            Piece p;
+            load_fields(L.slots[7], p);
+            while (!(p.flags & 1)) play(reinterpret_cast<uint16_t*>(L.slots[7]), p, cfg, mt_randint7(*M), nullptr);
+            L.misc[60] = (uint32_t)p.score;
+        }
+        wave_sync();
+        leaf_score = (int)L.misc[60];
+        for (int i = lane; i < 625; i += 64) ms[i] = (i < 624) ? M->mt[i] : M->idx;
+        wave_sync();
+    }
     if (!leaf_end && !overflow) {
         uint32_t lh;
         wave_expand(S, P, L, g, lane, leaf, lh);
-        if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT) {
+        if (kind == TM_KIND_VANILLA) {
+            k_eval = 0;
+            if (lane < S.eval_slots) P.eval_obs[lane] = 0;
+        } else if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT) {
             k_eval = 1;
             if (lane == 0) P.eval_obs[0] = (int)self_o;
         } else {
@@ -879,6 +927,7 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
 __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags) {
     __shared__ WaveLds lds[WPB];
     __shared__ float nq_lds[NQ_LDS];
+    extern __shared__ __attribute__((aligned(16))) MtLds mt_lds[];   // WPB entries, only for TM_KIND_VANILLA launches
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = blockIdx.x * WPB + w;
     if (flags & TM_SIM_FRONT) {
@@ -895,7 +944,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     }
     const long long t1 = __builtin_readcyclecounter();
     if (lane == 0) P.gs[TM_GS_CYC_BACK] = (int)(t1 - t0);
-    if (flags & TM_SIM_FRONT) wave_sim_front(S, P, L, nq_lds, g, lane);
+    if (flags & TM_SIM_FRONT) wave_sim_front(S, P, L, S.kind == TM_KIND_VANILLA ? &mt_lds[w] : nullptr, nq_lds, g, lane);
 }
 
 // agent.update_root(game) (agents/agent.py:296-301)
@@ -1109,7 +1158,8 @@ int tm_update_root(const tm_store* s, void* stream) {
     return TM_LAUNCH_CHECK();
 }
 int tm_sim_step(const tm_store* s, int flags, void* stream) {
-    hipLaunchKernelGGL(k_sim_step, dim3((s->n_games + WPB - 1) / WPB), dim3(64 * WPB), 0, (hipStream_t)stream, *s, flags);
+    size_t dyn = (s->kind == TM_KIND_VANILLA) ? WPB * sizeof(MtLds) : 0;
+    hipLaunchKernelGGL(k_sim_step, dim3((s->n_games + WPB - 1) / WPB), dim3(64 * WPB), dyn, (hipStream_t)stream, *s, flags);
     return TM_LAUNCH_CHECK();
 }
 int tm_eval_render(const tm_store* s, int8_t* out, void* stream) {
@@ -1132,7 +1182,7 @@ int tm_export_game(const tm_store* s, int game, int32_t* child, float* score, in
 // layout self-description so the host mirror (ctypes) can be checked without a GPU
 extern "C" int tm_store_layout(int* out, int n) {
     int v[] = {(int)sizeof(tm_store), (int)offsetof(tm_store, gamma), (int)offsetof(tm_store, node_rec),
-               (int)offsetof(tm_store, nq_table), (int)offsetof(tm_store, replay_count)};
+               (int)offsetof(tm_store, nq_table), (int)offsetof(tm_store, replay_count), (int)offsetof(tm_store, mt_state)};
     int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < m; ++i) out[i] = v[i];
     return m;

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 
 SIM_BACKUP, SIM_FRONT = 1, 2
-KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT = 0, 1, 2, 3
+KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA = 0, 1, 2, 3, 4
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17,
           CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22)
@@ -70,6 +70,7 @@ class TreeStore:
             gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N),
             replay_obs=z(G, max(replay_cap, 1), 12), replay_stat=z(G, max(replay_cap, 1), 4, dtype=torch.float32),
             replay_count=z(G),
+            mt_state=z(G if kind == KIND_VANILLA else 1, 625),
         )
         self.t["nq_table"] = norm_quantile_table(nq_size, dev)
         s = _lib.TmStore()
@@ -84,6 +85,12 @@ class TreeStore:
         self.action_buf = torch.zeros(G, dtype=torch.int32, device=dev)
         self.eval_states = torch.zeros(G * eval_slots, 200, dtype=torch.int8, device=dev)
         _lib.check(self.L.tm_pool_init(C.byref(s), _stream()), "tm_pool_init")
+
+    def set_python_random_states(self, states):
+        """states: one `random.getstate()` / `random.Random(seed).getstate()` per game (Vanilla's rollout RNG)."""
+        arr = np.stack([np.asarray(st[1], dtype=np.uint64).astype(np.uint32) for st in states])
+        assert arr.shape == (self.n_games, 625)
+        self.t["mt_state"].copy_(torch.from_numpy(arr.view(np.int32)))
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self.t.values())
