@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t rnd32(uint32_t seed, uint32_t ctr) {
     return (uint32_t)(splitmix64(((uint64_t)seed << 32) | ctr) >> 32);
 }
 // ENGINE_SPEC.md section 6
-__device__ inline int piece_at(uint32_t seed, uint32_t i, int randomizer) {
+__device__ __forceinline__ int piece_at(uint32_t seed, uint32_t i, int randomizer) {
     if (randomizer == 1) return (int)(rnd32(seed, i) % 7u);
     uint32_t k = i / 7u;
     // perm packed as 7 nibbles
@@ -121,7 +121,7 @@ __device__ __forceinline__ bool collides(const uint16_t* rows, uint32_t mask, in
     return hit != 0;
 }
 
-__device__ inline void spawn(const uint16_t* rows, Piece& p, const EngCfg& cfg) {
+__device__ __forceinline__ void spawn(const uint16_t* rows, Piece& p, const EngCfg& cfg) {
     p.piece = piece_at(p.seed, p.piece_count, cfg.randomizer);
     p.piece_count += 1;
     p.rot = 0; p.x = 3; p.y = 0; p.drop_ctr = 0;
@@ -129,7 +129,7 @@ __device__ inline void spawn(const uint16_t* rows, Piece& p, const EngCfg& cfg) 
 }
 
 // ENGINE_SPEC.md section 5.  line_stats (may be null) is a per-environment side record.
-__device__ inline void lock_piece(uint16_t* rows, Piece& p, const EngCfg& cfg, int* line_stats) {
+__device__ __forceinline__ void lock_piece(uint16_t* rows, Piece& p, const EngCfg& cfg, int* line_stats) {
     uint32_t mask = PIECE_MASK[p.piece][p.rot];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -165,7 +165,7 @@ __device__ inline void lock_piece(uint16_t* rows, Piece& p, const EngCfg& cfg, i
 }
 
 // ENGINE_SPEC.md section 4: one play(a)
-__device__ inline void play(uint16_t* rows, Piece& p, const EngCfg& cfg, int a, int* line_stats) {
+__device__ __forceinline__ void play(uint16_t* rows, Piece& p, const EngCfg& cfg, int a, int* line_stats) {
     if (p.flags & 1) return;
     bool locked = false;
     uint32_t mask = PIECE_MASK[p.piece][p.rot];

@@ -202,7 +202,7 @@ __device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, u
 
 __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane);
 
-__device__ inline void wave_new_nodes(const tm_store& S, const GP& P, WaveLds& L, int g, int n, int lane,
+__device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, WaveLds& L, int g, int n, int lane,
                                       int& r_idx, int& r_obs) {
     const bool act = lane < n;
     const uint32_t* my = L.slots[act ? lane : 0];
@@ -298,7 +298,7 @@ __device__ inline void wave_new_nodes(const tm_store& S, const GP& P, WaveLds& L
 // with the unique-child list of get_unique_child_obs (core.h:111-144).
 // Per-lane outputs for lane a < 7: child node / obs / score bits.  Returns false on pool exhaustion.
 // ---------------------------------------------------------------------------------------------------
-__device__ inline bool wave_expand(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
+__device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
                                    uint32_t& hdr_out) {
     if (lane < GAME_DW) L.slots[7][lane] = P.game[(size_t)leaf * GAME_DW + lane];
     wave_sync();
@@ -525,7 +525,7 @@ __device__ inline bool trace_has_repeat(const GP& P, WaveLds& L, int lane, int l
 // ---------------------------------------------------------------------------------------------------
 // the back half of a simulation: ValueSim.py:83-94 / ValueSimLP.py:59-70 / agent.cpp:432-446,458
 // ---------------------------------------------------------------------------------------------------
-__device__ inline void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L, int lane) {
+__device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L, int lane) {
     const int len = P.gs[TM_GS_TRACE_LEN];
     const int leaf_end = P.gs[TM_GS_LEAF_END];
     const int k = P.gs[TM_GS_K_EVAL];
@@ -596,7 +596,8 @@ __device__ inline void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L,
 // ---------------------------------------------------------------------------------------------------
 // the front half: select_trace_obs (core.h:167-224), then expansion and evaluation requests
 // ---------------------------------------------------------------------------------------------------
-__device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, const float* nq_lds, int g, int lane) {
+template <bool VANILLA>
+__device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, const float* nq_lds, int g, int lane) {
     const long long tc_start = __builtin_readcyclecounter();
     uint32_t rs = (lane < 32) ? S.rng[(size_t)g * 32 + lane] : 0u;   // glibc rand() state word i in lane i
     int rng_pos = P.gs[TM_GS_RNG_POS];
@@ -707,7 +708,7 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
     int leaf_score = (int)P.game[(size_t)leaf * GAME_DW + 14];
     if (overflow) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_TRACE); }
     const int kind = S.kind;
-    if (kind == TM_KIND_VANILLA && !leaf_end && !overflow) {
+    if (VANILLA && !leaf_end && !overflow) {
         // Vanilla.py:47-55: play a copy of the leaf to the end with uniformly random actions, value = final score
         uint32_t* ms = S.mt_state + (size_t)g * 625;
         for (int i = lane; i < 625; i += 64) { if (i < 624) M->mt[i] = ms[i]; else M->idx = ms[i]; }
@@ -728,7 +729,7 @@ __device__ inline void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L
     if (!leaf_end && !overflow) {
         uint32_t lh;
         wave_expand(S, P, L, g, lane, leaf, lh);
-        if (kind == TM_KIND_VANILLA) {
+        if (VANILLA) {
             k_eval = 0;
             if (lane < S.eval_slots) P.eval_obs[lane] = 0;
         } else if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT) {
@@ -924,10 +925,11 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
+template <bool VANILLA>
 __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags) {
     __shared__ WaveLds lds[WPB];
     __shared__ float nq_lds[NQ_LDS];
-    extern __shared__ __attribute__((aligned(16))) MtLds mt_lds[];   // WPB entries, only for TM_KIND_VANILLA launches
+    extern __shared__ __attribute__((aligned(16))) MtLds mt_lds[];   // WPB entries, only in the VANILLA instantiation
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = blockIdx.x * WPB + w;
     if (flags & TM_SIM_FRONT) {
@@ -944,7 +946,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     }
     const long long t1 = __builtin_readcyclecounter();
     if (lane == 0) P.gs[TM_GS_CYC_BACK] = (int)(t1 - t0);
-    if (flags & TM_SIM_FRONT) wave_sim_front(S, P, L, S.kind == TM_KIND_VANILLA ? &mt_lds[w] : nullptr, nq_lds, g, lane);
+    if (flags & TM_SIM_FRONT) wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, nq_lds, g, lane);
 }
 
 // agent.update_root(game) (agents/agent.py:296-301)
@@ -1158,8 +1160,11 @@ int tm_update_root(const tm_store* s, void* stream) {
     return TM_LAUNCH_CHECK();
 }
 int tm_sim_step(const tm_store* s, int flags, void* stream) {
-    size_t dyn = (s->kind == TM_KIND_VANILLA) ? WPB * sizeof(MtLds) : 0;
-    hipLaunchKernelGGL(k_sim_step, dim3((s->n_games + WPB - 1) / WPB), dim3(64 * WPB), dyn, (hipStream_t)stream, *s, flags);
+    const dim3 grid((s->n_games + WPB - 1) / WPB), block(64 * WPB);
+    if (s->kind == TM_KIND_VANILLA)
+        hipLaunchKernelGGL(k_sim_step<true>, grid, block, WPB * sizeof(MtLds), (hipStream_t)stream, *s, flags);
+    else
+        hipLaunchKernelGGL(k_sim_step<false>, grid, block, 0, (hipStream_t)stream, *s, flags);
     return TM_LAUNCH_CHECK();
 }
 int tm_eval_render(const tm_store* s, int8_t* out, void* stream) {
