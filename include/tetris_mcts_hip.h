@@ -38,6 +38,7 @@ enum {
     TM_GS_LEAF, TM_GS_LEAF_END, TM_GS_K_EVAL, TM_GS_LEAF_SCORE,
     TM_GS_TRACE_SUM, /* sum of trace lengths over all simulations (for bytes/simulation accounting) */
     TM_GS_N_EVAL,    /* leaf states handed to the evaluator */
+    TM_GS_N_POOL_RESET, /* tm_pool_reset calls that hit this game */
     TM_GS_CYC_BACK = 20, TM_GS_CYC_SELECT, TM_GS_CYC_EXPAND, TM_GS_CYC_TAIL  /* shader cycles of the last simulation's phases */
 };
 /* error bits in TM_GS_ERR */
@@ -99,6 +100,9 @@ typedef struct tm_store {
 
 /* pools, free lists, tables, rng (seed 1), control blocks.  Everything else must be zero-filled by the caller. */
 int tm_pool_init(const tm_store *s, void *stream);
+/* re-initialise the trees of the games with mask[g] != 0 (pool exhausted beyond what GC can reclaim; the reference has
+ * undefined behaviour there, agent.cpp:227-231); clears TM_ERR_POOL; the caller re-roots with tm_update_root */
+int tm_pool_reset(const tm_store *s, const uint8_t *mask, void *stream);
 /* host helper: fills host_table[n] = (float)norm_quantile((double)i) with this machine's libm */
 void tm_fill_norm_quantile(float *host_table, int n);
 

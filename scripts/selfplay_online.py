@@ -1,0 +1,73 @@
+"""Online self-play learning curve: batched ValueSimLP with GC-harvested TD targets and periodic fits of the value net
+(the reference's `python play.py --agent_type ValueSimLP --online ...`, README.md:36, scaled to many games at once).
+Writes one JSON line per training round: episodes finished since the last round and their mean lines / score."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tetris_mcts_amd import agents, model as M  # noqa: E402
+from tetris_mcts_amd.pyTetris import Tetris  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--games", type=int, default=512)
+ap.add_argument("--sims", type=int, default=200)
+ap.add_argument("--agent", default="ValueSimLP")
+ap.add_argument("--max-nodes", type=int, default=30000)
+ap.add_argument("--minutes", type=float, default=8.0)
+ap.add_argument("--train-every", type=int, default=100, help="moves between training attempts")
+ap.add_argument("--train-iters", type=int, default=3000)
+ap.add_argument("--out", default="gpurun_out/online_learning.jsonl")
+args = ap.parse_args()
+
+M.EXP_PATH = "/tmp/tm_ckpt/"
+os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+G = args.games
+env_args = ((20, 10), 1, 0, 0)
+game = Tetris(*env_args, seed=1234, n_games=G)
+model = M.Model_VV(backend="hip", seed=0)
+agent = getattr(agents, args.agent)(sims=args.sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=args.max_nodes,
+                                    model=model, online=True, replay_cap=8192)
+agent.update_root(game)
+t0 = time.time()
+moves, rounds = 0, 0
+ep_lines, ep_scores, ep_len = [], [], []
+alive = np.zeros(G, np.int64)
+log = open(args.out, "w")
+while time.time() - t0 < args.minutes * 60:
+    act = agent.play()
+    game.play(act)
+    agent.update_root(game)
+    moves += 1
+    alive += 1
+    ended = game.end
+    if ended.any():
+        ep_lines += list(game.line_clears[ended])
+        ep_scores += list(game.score[ended])
+        ep_len += list(alive[ended])
+        alive[ended] = 0
+        game.reset("ended")
+        agent.update_root(game)
+    if moves % args.train_every == 0:
+        tuples = int(agent.store.t["replay_count"].sum().item())
+        tt = time.time()
+        res = agent.train_nodes(iters_per_val=100, batch_size=1024, max_iters=args.train_iters, log=False)
+        rounds += 1
+        rec = dict(round=rounds, t=round(time.time() - t0, 1), moves=moves, episodes=len(ep_lines),
+                   mean_lines=float(np.mean(ep_lines)) if ep_lines else None,
+                   max_lines=int(np.max(ep_lines)) if ep_lines else None,
+                   mean_score=float(np.mean(ep_scores)) if ep_scores else None,
+                   mean_episode_moves=float(np.mean(ep_len)) if ep_len else None,
+                   new_tuples=tuples, trained=res is not None, train_iters=(res or {}).get("iters"),
+                   best_val=(res or {}).get("best_validation"), train_s=round(time.time() - tt, 1),
+                   gcs=agent.store.counter("N_GC"))
+        log.write(json.dumps(rec) + "\n")
+        log.flush()
+        print(rec, flush=True)
+        ep_lines, ep_scores, ep_len = [], [], []
+log.close()

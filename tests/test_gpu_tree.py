@@ -298,3 +298,23 @@ def test_vanilla_batch_vs_oracle(oracle):
                 og[g].reset()
                 oa[g].update_root(og[g])
     assert agent.store.counter("N_GC") == sum(o.n_gc for o in oa)
+
+
+def test_pool_exhaustion_resets_the_tree_instead_of_undefined_behaviour():
+    """A pool smaller than the reachable tree: the reference prints MAX_NODES EXCEEDED and runs into UB
+    (agent.cpp:227-231); here the affected games restart with an empty tree and play on."""
+    game, agent = _make("ValueSim", 8, 80, 400, 3, evaluator=hash_eval_torch)
+    for m in range(40):
+        act = agent.play()
+        game.play(act)
+        agent.update_root(game)
+        if game.end.any():
+            game.reset("ended")
+            agent.update_root(game)
+    assert agent.store.counter("N_POOL_RESET") > 0
+    assert (agent.store.errors() == 0).all()
+    strict = _make("ValueSim", 2, 80, 400, 3, evaluator=hash_eval_torch, reset_on_pool_exhaustion=False)[1]
+    with pytest.raises(RuntimeError):
+        for m in range(40):
+            strict.play()
+            strict.store.sim_step(0)

@@ -28,6 +28,7 @@ class TmStore(C.Structure):
 # every symbol include/tetris_mcts_hip.h declares
 SYMBOLS = {
     "tm_pool_init": [C.POINTER(TmStore), vp],
+    "tm_pool_reset": [C.POINTER(TmStore), vp, vp],
     "tm_env_init": [C.POINTER(TmStore), vp, vp],
     "tm_env_step": [C.POINTER(TmStore), vp, vp],
     "tm_env_reset": [C.POINTER(TmStore), vp, vp],

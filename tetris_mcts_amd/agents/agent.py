@@ -49,7 +49,7 @@ class TreeAgent(Agent):
 
     def __init__(self, sims=100, max_nodes=500000, env=None, env_args=None, node_saver=None, projection=True,
                  min_visits=30, n_games=None, gamma=0.999, online=False, min_visits_to_store=10, replay_cap=0,
-                 max_trace=1024, nq_size=1 << 20, use_graph=True, **kwargs):
+                 max_trace=1024, nq_size=1 << 20, use_graph=True, reset_on_pool_exhaustion=True, **kwargs):
         super().__init__(**kwargs)
         if not projection:
             raise NotImplementedError("projection=False is broken in the reference itself (ValueSim.py:73-74)")
@@ -65,6 +65,8 @@ class TreeAgent(Agent):
                                   min_visits_to_store=min_visits_to_store, replay_cap=replay_cap, max_trace=max_trace,
                                   nq_size=nq_size)
         self.store = None
+        self.reset_on_pool_exhaustion = reset_on_pool_exhaustion
+        self._pending_pool_reset = None
         self.use_graph = use_graph
         self._graph = None
         self.stats = None
@@ -128,7 +130,17 @@ class TreeAgent(Agent):
         err = self.store.errors()
         a = action.cpu().numpy()
         if bool((err != 0).any().item()):
-            raise RuntimeError("tree engine error flags: %s" % sorted(set(err.cpu().numpy().tolist())))
+            pool = (err & 1) != 0
+            if self.reset_on_pool_exhaustion and bool(((err & ~1) == 0).all().item()):
+                # The reachable tree outgrew the pool (the reference prints "MAX_NODES EXCEEDED" and runs into undefined
+                # behaviour, agent.cpp:227-231).  Those games keep the action of the search done so far and restart
+                # with an empty tree at their next update_root.
+                from sys import stderr
+                print("MAX_NODES EXCEEDED in %d game(s): their trees are re-initialised" % int(pool.sum().item()),
+                      file=stderr, flush=True)
+                self._pending_pool_reset = pool.clone()
+            else:
+                raise RuntimeError("tree engine error flags: %s" % sorted(set(err.cpu().numpy().tolist())))
         return int(a[0]) if self.n_games == 1 else a
 
     def get_stats(self):
@@ -156,6 +168,9 @@ class TreeAgent(Agent):
         if self.store is None:
             self._build(getattr(game, "n_games", 1))
         self.store.set_root_games(game.games)
+        if self._pending_pool_reset is not None:
+            self.store.pool_reset(self._pending_pool_reset)
+            self._pending_pool_reset = None
         self.store.update_root()
         ended = np.atleast_1d(game.end)
         self.episode += int(ended.sum())

@@ -1019,6 +1019,35 @@ __global__ void k_pool_init(tm_store S) {
     }
 }
 
+// Re-initialise the trees of the games selected by mask (pool exhausted beyond what GC can reclaim: the reference has
+// undefined behaviour there, agent.cpp:227-231).  Episode counter, rand() stream and statistics counters survive.
+__global__ void k_pool_reset(tm_store S, const uint8_t* mask) {
+    const int g = blockIdx.x;
+    if (!mask[g]) return;
+    GP P = game_ptrs(S, g);
+    const int N = S.max_nodes;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    uint4* rec = reinterpret_cast<uint4*>(P.rec);
+    for (size_t i = threadIdx.x; i < (size_t)N * TM_REC_DW / 4; i += blockDim.x) rec[i] = z;
+    uint4* gm = reinterpret_cast<uint4*>(P.game);
+    for (size_t i = threadIdx.x; i < (size_t)N * GAME_DW / 4; i += blockDim.x) gm[i] = z;
+    uint4* stt = reinterpret_cast<uint4*>(P.stat);
+    for (size_t i = threadIdx.x; i < (size_t)N; i += blockDim.x) stt[i] = z;
+    uint4* ok = reinterpret_cast<uint4*>(P.okey);
+    for (size_t i = threadIdx.x; i < (size_t)N * OBS_DW / 4; i += blockDim.x) ok[i] = z;
+    for (size_t i = threadIdx.x; i < (size_t)S.table_cap; i += blockDim.x) { P.ntab[i] = 0; P.otab[i] = 0; }
+    for (int i = threadIdx.x; i < N - 1; i += blockDim.x) { P.fnode[i] = i + 1; P.fobs[i] = i + 1; }
+    if (threadIdx.x == 0) {
+        P.gs[TM_GS_ROOT] = 0;
+        P.gs[TM_GS_NFREE_NODE] = N - 1;
+        P.gs[TM_GS_NFREE_OBS] = N - 1;
+        P.gs[TM_GS_TRACE_LEN] = 0;
+        P.gs[TM_GS_PENDING] = 0;
+        P.gs[TM_GS_ERR] &= ~TM_ERR_POOL;
+        P.gs[TM_GS_N_POOL_RESET] += 1;
+    }
+}
+
 // ---- environment kernels: one lane per game, 64-byte LDS slot per lane ----
 __global__ __launch_bounds__(64) void k_env_init(tm_store S, const uint32_t* seeds) {
     __shared__ uint32_t slots[64][GAME_DW];
@@ -1133,6 +1162,10 @@ void tm_fill_norm_quantile(float* t, int n) {
 
 int tm_pool_init(const tm_store* s, void* stream) {
     hipLaunchKernelGGL(k_pool_init, dim3(s->n_games), dim3(256), 0, (hipStream_t)stream, *s);
+    return TM_LAUNCH_CHECK();
+}
+int tm_pool_reset(const tm_store* s, const uint8_t* mask, void* stream) {
+    hipLaunchKernelGGL(k_pool_reset, dim3(s->n_games), dim3(256), 0, (hipStream_t)stream, *s, mask);
     return TM_LAUNCH_CHECK();
 }
 int tm_env_init(const tm_store* s, const uint32_t* seeds, void* stream) {

@@ -13,7 +13,7 @@ from . import _lib
 SIM_BACKUP, SIM_FRONT = 1, 2
 KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA = 0, 1, 2, 3, 4
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
-          RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17,
+          RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18,
           CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22)
 
 _nq_cache = {}
@@ -114,6 +114,11 @@ class TreeStore:
         _lib.check(self.L.tm_root_stats(C.byref(self.s), _p(self.stats_buf), _p(self.action_buf), _stream()),
                    "tm_root_stats")
         return self.stats_buf, self.action_buf
+
+    def pool_reset(self, mask):
+        """Re-initialise the trees of the games where mask is true (uint8/bool [G], device)."""
+        m = mask.to(torch.uint8).contiguous()
+        _lib.check(self.L.tm_pool_reset(C.byref(self.s), _p(m), _stream()), "tm_pool_reset")
 
     def errors(self):
         return self.t["gs"][:, GS["ERR"]]
