@@ -824,7 +824,9 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
         int off = tail + incl - cnt;
         for (int j = 0; j < cnt; ++j) queue[off + j] = (int)cs[j];
         tail += total;
-        __threadfence();
+        // the queue is produced and consumed by this wave only: a workgroup-scope fence (wait for the stores, same-CU
+        // L1 is write-through) is enough, the device-scope one (L2 write-back + L1 invalidate) cost microseconds per batch
+        __threadfence_block();
     }
     // the root of an unexpanded tree still reaches node 0 through its zero child row
     __threadfence();
