@@ -15,6 +15,8 @@ import os
 import sys
 import time
 
+np = None
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -47,6 +49,7 @@ def bytes_per_sim(mean_trace_len, k_eval):
 
 
 def main():
+    global np
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -241,9 +244,57 @@ def main():
 
 
 def cpu_baseline(args, model):
-    """The oracle's C restatement of the same agent (kind 'port'), 1 thread, on this box's host cores: a bounded
-    sample of the same workload (1 game, same sims/move, same network weights)."""
+    """CPU baseline on this box's host cores, 1 thread, bounded sample of the same workload (1 game, same sims/move,
+    same network weights).  Preferred: kind "reference" = the reference's own all-C++ MCTSAgent (agents/cppmodule/
+    agent.cpp compiled in place into oracle/_ref/, the ValueSimC path) with a single-thread torch CPU evaluator.
+    Fallback / secondary: kind "port" = the oracle's C restatement incl. its fma-chain value net."""
+    import torch
     from oracle import binding as B
+    out = None
+    lp = args.agent != "ValueSim"
+    try:
+        agent_mod = B.load_ref_native("agent")
+        if agent_mod is not None:
+            sys.path.insert(0, B.BUILD)
+            from pyTetris import Tetris as OTetris
+            from tetris_mcts_amd.model import Net
+            torch.set_num_threads(1)
+            net = Net().eval()
+            net.load_state_dict({k: v.detach().cpu() for k, v in model.model.state_dict().items()})
+            n_calls = [0, 0]
+
+            def ev(obs):
+                x = torch.from_numpy(np.asarray(obs).astype(np.float32))
+                with torch.no_grad():
+                    y = net(x.reshape(-1, 1, 20, 10))
+                n_calls[0] += 1
+                n_calls[1] += y.shape[0]
+                if lp:
+                    return [y[:, 0].tolist(), y[:, 1].tolist()]
+                return [float(y[0, 0]), float(y[0, 1])]
+            import ctypes
+            ctypes.CDLL("libc.so.6").srand(1)
+            ag = agent_mod.MCTSAgent(args.sims, args.max_nodes, True, 0.999, False, ev, 0, lp)
+            g = OTetris((20, 10), 1, 0, 0, 20260925)
+            ag.update_root(g)
+            t0 = time.perf_counter()
+            moves = 0
+            while time.perf_counter() - t0 < args.cpu_seconds:
+                g.play(int(ag.play()))
+                ag.update_root(g)
+                moves += 1
+                if g.end:
+                    g.reset()
+                    ag.update_root(g)
+            dt = time.perf_counter() - t0
+            out = {"value": n_calls[0] / dt, "unit": "node-expansions/s", "cores": 1, "kind": "reference",
+                   "sample": "1 game x %d moves x %d sims/move, the reference's own MCTSAgent (agent.cpp compiled in place, "
+                             "LP=%s) + torch CPU Net, 1 thread, %.1f s" % (moves, args.sims, lp, dt),
+                   "sims_per_sec": moves * args.sims / dt, "evaluated_states_per_sec": n_calls[1] / dt,
+                   "host_cpus": os.cpu_count()}
+    except Exception as e:  # the reference build is optional on the GPU box
+        out = None
+        sys.stderr.write("reference CPU baseline unavailable (%s); using the oracle port\n" % (e,))
     kind = 0 if args.agent == "ValueSim" else 1
     params = model.flat_params().cpu().numpy()
     g = B.Game(seed=20260925)
@@ -251,7 +302,8 @@ def cpu_baseline(args, model):
     a.update_root(g)
     t0 = time.perf_counter()
     moves = 0
-    while time.perf_counter() - t0 < args.cpu_seconds:
+    budget = args.cpu_seconds if out is None else min(args.cpu_seconds, 5.0)
+    while time.perf_counter() - t0 < budget:
         g.play(a.play(args.sims))
         a.update_root(g)
         moves += 1
@@ -259,10 +311,14 @@ def cpu_baseline(args, model):
             g.reset()
             a.update_root(g)
     dt = time.perf_counter() - t0
-    return {"value": a.n_expand / dt, "unit": "node-expansions/s", "cores": 1, "kind": "port",
+    port = {"value": a.n_expand / dt, "unit": "node-expansions/s", "cores": 1, "kind": "port",
             "sample": "1 game x %d moves x %d sims/move, oracle C restatement of %s incl. fp32 value net, %.1f s" %
                       (moves, args.sims, args.agent, dt),
             "sims_per_sec": a.n_sims / dt, "host_cpus": os.cpu_count()}
+    if out is None:
+        return port
+    out["port"] = port
+    return out
 
 
 if __name__ == "__main__":
