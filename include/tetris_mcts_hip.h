@@ -23,7 +23,12 @@ extern "C" {
 #define TM_NACT 7
 #define TM_GAME_DW 16      /* packed game, ENGINE_SPEC.md section 2 (64 bytes) */
 #define TM_OBS_DW 12       /* packed observation, ENGINE_SPEC.md section 7 (48 bytes) */
-#define TM_REC_DW 24       /* node record (96 bytes), see DESIGN.md "node store" */
+#define TM_REC_DW 24       /* node record (96 bytes): 7 x (child, obs, score bits) unique children in selection order,
+                              then TM_REC_HDR, TM_REC_OBS, TM_REC_SCORE; see DESIGN.md "node store" */
+#define TM_REC_HDR 21      /* bits 0-2 number of unique children, bit 24 game ended, bit 25 expanded */
+#define TM_REC_OBS 22      /* node_to_obs */
+#define TM_REC_SCORE 23    /* float32 score of the node's game */
+#define TM_KIDS_DW 8       /* raw children row: child[7] in action order + pad */
 #define TM_GS_DW 32        /* per-game control block */
 #define TM_LEAF_DW 32      /* per-game leaf hand-off between the front and back halves of a simulation */
 #define TM_VALUENET_PARAMS 478342
@@ -71,7 +76,7 @@ typedef struct tm_store {
     int32_t replay_cap;   /* capacity (tuples) of the replay buffer */
     double gamma;
     /* node store, per game contiguous */
-    uint32_t *node_rec;   /* [G][N][24] hdr, self_obs, self_score, child[7], child_obs[7], child_score[7] */
+    uint32_t *node_rec;   /* [G][N][24] 7 x (child, obs, score) unique children in selection order, hdr, self_obs, self_score */
     uint32_t *node_game;  /* [G][N][16] packed game */
     uint32_t *obs_stat;   /* [G][N][4]  visit(i32), value(f32), variance(f32), end(u32) */
     uint32_t *obs_key;    /* [G][N][12] packed observation */
@@ -96,6 +101,7 @@ typedef struct tm_store {
     float *replay_stat;   /* [G][replay_cap][4] value, variance, visit, 0 */
     int32_t *replay_count;/* [G] */
     uint32_t *mt_state;   /* [G][625] CPython random state per game (624 words + index), TM_KIND_VANILLA rollouts (Vanilla.py:4,52) */
+    uint32_t *node_child; /* [G][N][8] raw child[7] per action (agents/agent.py:61) + pad */
 } tm_store;
 
 /* pools, free lists, tables, rng (seed 1), control blocks.  Everything else must be zero-filled by the caller. */

@@ -32,7 +32,7 @@ class Agent:
         s = self.store
         g = torch.arange(self.n_games, device=s.device)
         root = s.t["gs"][:, st.GS["ROOT"]].long()
-        o = s.t["node_rec"][g, root, 1].long()
+        o = s.t["node_rec"][g, root, 22].long()
         vv = s.t["obs_stat"][g, o, 1:3].view(torch.float32).cpu().numpy()
         return (vv[0, 0], vv[0, 1]) if self.n_games == 1 else (vv[:, 0], vv[:, 1])
 
@@ -160,7 +160,7 @@ class TreeAgent(Agent):
         s = self.store
         g = torch.arange(self.n_games, device=s.device)
         root = s.t["gs"][:, st.GS["ROOT"]].long()
-        o = s.t["node_rec"][g, root, 1].long()
+        o = s.t["node_rec"][g, root, 22].long()
         vv = s.t["obs_stat"][g, o, 1:3].view(torch.float32).cpu().numpy()
         return (vv[0, 0], vv[0, 1]) if self.n_games == 1 else (vv[:, 0], vv[:, 1])
 

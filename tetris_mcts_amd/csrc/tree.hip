@@ -7,9 +7,10 @@
 //   backup_trace_obs       core.h:226-260 ; backup_trace_obs_LP core.h:303-381 ;
 //   MCTSAgent twins        agent.cpp:496-566
 //   compute_stats/get_action agents/agent.py:153-185
-// Layout and kernel design: DESIGN.md.  Node record (96 B) keeps, next to the child indices, each
-// child's observation index and score and the precomputed unique-child list, so a tree level costs two
-// dependent memory round trips (record, then the <=7 observation statistics) instead of three.
+// Layout and kernel design: DESIGN.md.  Node record (96 B) = the node's unique children in selection order as
+// (child, observation, score) triples + (header, own observation, own score): get_unique_child_obs is evaluated
+// once, at expansion, and a tree level costs one memory round trip (children's statistics + speculative prefetch
+// of the children's records).  The raw per-action child indices live in a separate 32-byte row (GC, root statistics).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "engine.cuh"
@@ -57,7 +58,7 @@ __device__ inline int mt_randint7(MtLds& m) {
 }
 
 struct GP {  // base pointers of one game
-    uint32_t *rec, *game, *stat, *okey;
+    uint32_t *rec, *game, *stat, *okey, *kids;
     uint64_t *ntab, *otab;
     int32_t *fnode, *fobs, *gs, *leaf, *eval_obs;
     uint32_t* trace;
@@ -68,6 +69,7 @@ __device__ __forceinline__ GP game_ptrs(const tm_store& S, int g) {
     GP P;
     size_t n = (size_t)S.max_nodes, gg = (size_t)g;
     P.rec = S.node_rec + gg * n * TM_REC_DW;
+    P.kids = S.node_child + gg * n * TM_KIDS_DW;
     P.game = S.node_game + gg * n * TM_GAME_DW;
     P.stat = S.obs_stat + gg * n * 4;
     P.okey = S.obs_key + gg * n * TM_OBS_DW;
@@ -89,9 +91,16 @@ __device__ __forceinline__ uint32_t shfl_u32(uint32_t v, int src) { return (uint
 // wave-uniform source lane: v_readlane_b32 (scalar path, a few cycles) instead of an LDS-crossbar ds_bpermute
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 __device__ __forceinline__ float rl_f32(float v, int src) { return __uint_as_float(rl_u32(__float_as_uint(v), src)); }
+// DPP exchanges inside an 8-lane group (no LDS, no scalar round trip): partner = lane^1, lane^2, 7-lane
+__device__ __forceinline__ uint32_t dpp_x1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t dpp_x2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t dpp_hm(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true); }
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     uint32_t lo = shfl_u32((uint32_t)v, src), hi = shfl_u32((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t rl_u64(uint64_t v, int src) {   // wave-uniform source lane
+    return ((uint64_t)rl_u32((uint32_t)(v >> 32), src) << 32) | rl_u32((uint32_t)v, src);
 }
 __device__ __forceinline__ double shfl_f64(double v, int src) {
     return __longlong_as_double((long long)shfl_u64((uint64_t)__double_as_longlong(v), src));
@@ -211,7 +220,7 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     // 1. candidates that are equal to an earlier candidate reuse its node (dict hit in the reference)
     int dup = lane;
     for (int b = 0; b < n; ++b) {
-        uint64_t hb = shfl_u64(h, b);
+        uint64_t hb = rl_u64(h, b);
         if (act && dup == lane && b < lane && hb == h && eq_lds(my, L.slots[b], GAME_DW)) dup = b;
     }
     const bool uniq = act && dup == lane;
@@ -245,7 +254,7 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     wave_sync();
     int odup = lane;
     for (int b = 0; b < n; ++b) {
-        uint64_t hb = shfl_u64(ho, b);
+        uint64_t hb = rl_u64(ho, b);
         bool bnew = (need >> b) & 1ull;
         if (isnew && bnew && odup == lane && b < lane && hb == ho && eq_lds(ok, L.okeys[b], OBS_DW)) odup = b;
     }
@@ -280,11 +289,11 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         dst[2] = make_uint4(my[8], my[9], my[10], my[11]);
         dst[3] = make_uint4(my[12], my[13], my[14], my[15]);
         uint32_t* r = P.rec + (size_t)idx * TM_REC_DW;
-        r[0] = ((my[11] >> 8) & 1u) << 24;               // end flag of the node's game
-        r[1] = (uint32_t)o;                              // node_to_obs
-        r[2] = __float_as_uint((float)(int)my[14]);      // arrays['score'][idx] = game.score (float32)
+        r[TM_REC_HDR] = ((my[11] >> 8) & 1u) << 24;          // end flag of the node's game
+        r[TM_REC_OBS] = (uint32_t)o;                         // node_to_obs
+        r[TM_REC_SCORE] = __float_as_uint((float)(int)my[14]);   // arrays['score'][idx] = game.score (float32)
     }
-    if (uniq && found) o = (int)P.rec[(size_t)found * TM_REC_DW + 1];
+    if (uniq && found) o = (int)P.rec[(size_t)found * TM_REC_DW + TM_REC_OBS];
     {
         int isrc = shfl_u32((uint32_t)idx, dup), osrc = shfl_u32((uint32_t)o, dup);
         if (act && dup != lane) { idx = isrc; o = osrc; }
@@ -332,45 +341,32 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
                 wave_new_nodes(S, P, L, g, 1, lane, i1, o1);
                 if (i1 < 0) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_POOL); i1 = 0; o1 = 0; }
             }
-            i1 = (int)shfl_u32((uint32_t)i1, 0);
-            o1 = (int)shfl_u32((uint32_t)o1, 0);
+            i1 = (int)rl_u32((uint32_t)i1, 0);
+            o1 = (int)rl_u32((uint32_t)o1, 0);
             if (lane < GAME_DW) L.slots[0][lane] = keep;
             wave_sync();
             if (lane == a) { out_idx = i1; out_o = o1; }
             // the reference links child[idx][a] right after each new_node (agent.py:145), which is what
             // makes earlier successors reachable for a later GC
-            if (lane == 0) {
-                uint32_t* r = P.rec + (size_t)leaf * TM_REC_DW;
-                r[3 + a] = (uint32_t)i1;
-                r[10 + a] = (uint32_t)o1;
-                r[17 + a] = __float_as_uint((float)(int)L.slots[a][14]);
-            }
+            if (lane == 0) P.kids[(size_t)leaf * TM_KIDS_DW + a] = (uint32_t)i1;
             wave_sync();
         }
         idx = out_idx;
         o = out_o;
     }
     uint32_t sbits = __float_as_uint((float)(int)L.slots[lane < 7 ? lane : 0][14]);
-    if (lane < 7) {
-        uint32_t* r = P.rec + (size_t)leaf * TM_REC_DW;
-        r[3 + lane] = (uint32_t)idx;
-        r[10 + lane] = (uint32_t)o;
-        r[17 + lane] = sbits;
-        L.misc[16 + lane] = (uint32_t)idx;
-        L.misc[24 + lane] = (uint32_t)o;
-        L.misc[32 + lane] = sbits;
-    }
-    wave_sync();
+    if (lane < 7) P.kids[(size_t)leaf * TM_KIDS_DW + lane] = (uint32_t)idx;    // raw children, action order
     // get_unique_child_obs (core.h:126-142), evaluated once here because its inputs never change.  Lane a owns
-    // action a: "first" = earliest action with the same observation; the first lane of each group then scans the
-    // group in action order keeping the strictly-greater score (the reference's replacement rule) and the groups
-    // are compacted in first-seen order.
+    // action a: every lane scans the actions in order, finds the first action with its observation ("first") and,
+    // from there on, keeps the strictly-greater score (the reference's replacement rule).  The first lane of each
+    // group is its leader; leaders are compacted in first-seen order = the reference's c_nodes / c_obs order, and
+    // write their (representative child, observation, its score) triple into the record's slot.
     {
         const bool act7 = lane < 7;
         const uint32_t my_c = act7 ? (uint32_t)idx : 0u, my_o = act7 ? (uint32_t)o : 0u;
         const float my_s = __uint_as_float(sbits);
         int first = lane;
-        int best = lane;
+        uint32_t best_c = my_c;
         float best_s = my_s;
         bool seen_first = false;
 #pragma unroll
@@ -378,21 +374,26 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
             const uint32_t cb = rl_u32(my_c, b), ob = rl_u32(my_o, b);
             const float sb = rl_f32(my_s, b);
             const bool same = act7 && cb != 0 && my_c != 0 && ob == my_o;
-            if (same && !seen_first) { first = b; seen_first = true; best = b; best_s = sb; }
-            else if (same && sb > best_s) { best = b; best_s = sb; }
+            if (same && !seen_first) { first = b; seen_first = true; best_c = cb; best_s = sb; }
+            else if (same && sb > best_s) { best_c = cb; best_s = sb; }
         }
-        // only the group's first lane holds the full scan (it starts at itself); others started later or earlier,
-        // so recompute "best" from the first lane's point of view: lanes with first == lane are the leaders.
         const bool leader = act7 && my_c != 0 && first == lane;
         const uint64_t lead_mask = __ballot(leader);
         const int nu = __popcll(lead_mask);
         const int slot = __popcll(lead_mask & ((1ull << lane) - 1ull));
-        uint32_t hdr = (uint32_t)nu | (1u << 25);
-        // every leader contributes its representative action at its slot
-        uint32_t contrib = leader ? ((uint32_t)best << (3 + 3 * slot)) : 0u;
-#pragma unroll
-        for (int b = 0; b < 7; ++b) hdr |= rl_u32(contrib, b);
-        if (lane == 0) { L.misc[56] = hdr; P.rec[(size_t)leaf * TM_REC_DW] = hdr; }
+        const uint32_t hdr = (uint32_t)nu | (1u << 25);
+        uint32_t* r = P.rec + (size_t)leaf * TM_REC_DW;
+        if (lane < 7) { L.misc[16 + lane] = 0; L.misc[24 + lane] = 0; L.misc[32 + lane] = 0; }
+        wave_sync();
+        if (leader) {
+            r[3 * slot] = best_c;
+            r[3 * slot + 1] = my_o;
+            r[3 * slot + 2] = __float_as_uint(best_s);
+            L.misc[16 + slot] = best_c;                 // slot-ordered copies for the evaluation requests
+            L.misc[24 + slot] = my_o;
+            L.misc[32 + slot] = __float_as_uint(best_s);
+        }
+        if (lane == 0) { L.misc[56] = hdr; r[TM_REC_HDR] = hdr; }
     }
     wave_sync();
     hdr_out = L.misc[56];
@@ -608,17 +609,21 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     const int low = S.low;
     int nq_fallback = 0;
     bool overflow = false;
-    // Each level needs the node record and then the statistics of its <=7 unique child observations.  The
-    // records of those children are requested together with the statistics (168 dwords = 3 loads per lane), so
-    // the record of whichever child gets selected is already in registers: one memory round trip per level.
-    // Nothing is stored to global memory inside the walk (stores share the load counter on gfx9: a store per
-    // level would make every level wait for its acknowledgement); the trace goes through LDS and is flushed
-    // 128 entries at a time with coalesced 16-byte stores.
-    int pf_child[3], pf_word[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { int e = lane + 64 * r; pf_child[r] = e / TM_REC_DW; pf_word[r] = e - pf_child[r] * TM_REC_DW; }
-    const int my_slot = lane < 7 ? lane : 0;
-    uint32_t d = (lane < TM_REC_DW) ? P.rec[(size_t)idx * TM_REC_DW + lane] : 0u;
+    // Node record = 8 pieces of 3 dwords: pieces 0..6 are the unique children in selection order
+    // (child, observation, score), piece 7 is (header, own observation, own score).  Lane k < 8 holds piece k, so the
+    // children's fields are already in the lanes that evaluate them.  Per level ONE round of loads: the children's
+    // statistics (16 B, lanes 0..6) and, speculatively, the records of all unique children (lane 8t+k loads piece k
+    // of child t: one dwordx3 per lane) - whichever child is selected, its record is already in registers.
+    // Nothing is stored to global memory inside the walk (stores share the load counter on gfx9: a store per level
+    // would make every level wait for its acknowledgement); the trace goes through LDS and is flushed 64 entries at
+    // a time with coalesced 16-byte stores.
+    const int pf_t = lane >> 3, pf_k = lane & 7;
+    long long cyc_mem = 0;
+    uint32_t dx = 0, dy = 0, dz = 0;
+    if (lane < 8) {
+        const uint32_t* p = P.rec + (size_t)idx * TM_REC_DW + 3 * lane;
+        dx = p[0]; dy = p[1]; dz = p[2];
+    }
     int flushed = 0;
     auto flush_trace = [&](int upto) {   // entries [flushed, upto) from LDS to global, 64 per pass
         for (int base = flushed; base < upto; base += 64) {
@@ -628,36 +633,28 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         flushed = upto;
     };
     for (;;) {
-        hdr = rl_u32(d, 0);
-        self_o = rl_u32(d, 1);
-        uint32_t self_sc = rl_u32(d, 2);
+        hdr = rl_u32(dx, 7);
+        self_o = rl_u32(dy, 7);
+        uint32_t self_sc = rl_u32(dz, 7);
         if (len >= S.max_trace) { overflow = true; break; }
         if (len - flushed == TRACE_LDS) { wave_sync(); flush_trace(len); wave_sync(); }
         if (lane == 0) L.tbuf[len - flushed] = make_uint4((uint32_t)idx, self_o, self_sc, 0u);
         len += 1;
         const int nu = (int)(hdr & 7u);
         if (nu == 0) break;
-        // one round of cross-lane gathers, all sourced from the record itself (hdr is wave-uniform)
-        const int rep = (int)((hdr >> (3 + 3 * my_slot)) & 7u);
-        const uint32_t c = shfl_u32(d, 3 + rep), o = shfl_u32(d, 10 + rep);
-        const float sc = __uint_as_float(shfl_u32(d, 17 + rep));
-        uint32_t pcc[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            int t = pf_child[r] < 7 ? pf_child[r] : 0;
-            int rep_t = (int)((hdr >> (3 + 3 * t)) & 7u);
-            uint32_t cc = shfl_u32(d, 3 + rep_t);
-            pcc[r] = (pf_child[r] < nu) ? cc : 0u;     // slots past nu read node 0 (all zero, always valid)
-        }
         const bool on = lane < nu;
-        const uint32_t osafe = on ? o : 0u;
-        // one round of loads: statistics of the unique child observations + their records (speculative)
-        const uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)osafe * 4);
-        uint32_t pre[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) pre[r] = P.rec[(size_t)pcc[r] * TM_REC_DW + pf_word[r]];
+        const uint32_t c = on ? dx : 0u, o = on ? dy : 0u;     // empty slots / other lanes read entry 0 (always valid)
+        const float sc = __uint_as_float(dz);
+        // loads of this level: statistics of my child observation; piece pf_k of unique child pf_t
+        const long long tm_a = __builtin_readcyclecounter();
+        const uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
+        uint32_t ct = shfl_u32(c, pf_t < 7 ? pf_t : 0);
+        ct = (pf_t < nu) ? ct : 0u;
+        const uint32_t* pp = P.rec + (size_t)ct * TM_REC_DW + 3 * pf_k;
+        const uint32_t px = pp[0], py = pp[1], pz = pp[2];
         const int visit = on ? (int)st.x : 0;
         const uint64_t lowmask = __ballot(on && visit < low);
+        cyc_mem += __builtin_readcyclecounter() - tm_a;      // issue of the level's loads -> statistics available
         int sel;
         if (lowmask) {
             // check_low (core.h:65-77): a uniformly drawn under-visited child, libc rand()
@@ -668,10 +665,13 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
             for (int t = 0; t < kth; ++t) mm &= mm - 1;
             sel = __ffsll((long long)mm) - 1;
         } else {
-            // policy_clt (core.h:83-105): float arithmetic, one rounding per operation
-            int n = 0;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) { int vi = (int)rl_u32((uint32_t)visit, i); n += (i < nu) ? vi : 0; }
+            // policy_clt (core.h:83-105): float arithmetic, one rounding per operation.
+            // n = sum of the children's visits: butterfly over the 8-lane group (lanes >= nu hold 0)
+            uint32_t ns = (uint32_t)visit;
+            ns += dpp_x1(ns);
+            ns += dpp_x2(ns);
+            ns += dpp_hm(ns);
+            const int n = (int)rl_u32(ns, 0);
             float coeff;
             if (n < NQ_LDS && n < S.nq_size) coeff = nq_lds[n];
             else if (n < S.nq_size) coeff = S.nq_table[n];
@@ -683,20 +683,32 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
             float root = sqrtf(ratio);
             float prod = coeff * root;
             float q = val + prod;
-            sel = 0;
-            float max_q = rl_f32(q, 0);
-#pragma unroll
-            for (int i = 1; i < 7; ++i) {
-                float qi = rl_f32(q, i);
-                if (i < nu && qi > max_q) { max_q = qi; sel = i; }
+            // first-max argmax with the reference's scan semantics (max_q = q_0; i >= 1 replaces only if q_i > max_q):
+            // a NaN at i >= 1 never wins, a NaN at 0 is never replaced; ties keep the lower index.
+            float bq = on ? q : -INFINITY;
+            if (bq != bq) bq = (lane == 0) ? INFINITY : -INFINITY;
+            uint32_t bi = (uint32_t)lane;
+#define TM_ARGMAX_STEP(X)                                                                 \
+            {                                                                             \
+                const float pq = __uint_as_float(X(__float_as_uint(bq)));                 \
+                const uint32_t pi = X(bi);                                                \
+                const bool take = (pq > bq) || (pq == bq && pi < bi);                     \
+                bq = take ? pq : bq;                                                      \
+                bi = take ? pi : bi;                                                      \
             }
+            TM_ARGMAX_STEP(dpp_x1)
+            TM_ARGMAX_STEP(dpp_x2)
+            TM_ARGMAX_STEP(dpp_hm)
+#undef TM_ARGMAX_STEP
+            sel = (int)rl_u32(bi, 0);
         }
         idx = (int)rl_u32(c, sel);
-        {   // the selected child's record out of the prefetched block
-            int e = sel * TM_REC_DW + (lane < TM_REC_DW ? lane : 0);
-            uint32_t v0 = shfl_u32(pre[0], e & 63), v1 = shfl_u32(pre[1], e & 63), v2 = shfl_u32(pre[2], e & 63);
-            int r = e >> 6;
-            d = (lane < TM_REC_DW) ? (r == 0 ? v0 : (r == 1 ? v1 : v2)) : 0u;
+        {   // the selected child's record out of the prefetched block: piece k sits in lane 8*sel + k
+            const int src = sel * 8 + pf_k;
+            const uint32_t nx = shfl_u32(px, src), ny = shfl_u32(py, src), nz = shfl_u32(pz, src);
+            dx = (lane < 8) ? nx : 0u;
+            dy = (lane < 8) ? ny : 0u;
+            dz = (lane < 8) ? nz : 0u;
         }
     }
     wave_sync();
@@ -740,12 +752,11 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
             const int nu = (int)(lh & 7u);
             k_eval = nu;
             if (lane < 7) {
-                int rep = (int)((lh >> (3 + 3 * lane)) & 7u);
                 bool on = lane < nu;
-                P.leaf[lane] = on ? (int)L.misc[16 + rep] : 0;
-                P.leaf[7 + lane] = on ? (int)L.misc[24 + rep] : 0;
-                P.leaf[14 + lane] = on ? (int)L.misc[32 + rep] : 0;
-                P.eval_obs[lane] = on ? (int)L.misc[24 + rep] : 0;
+                P.leaf[lane] = on ? (int)L.misc[16 + lane] : 0;
+                P.leaf[7 + lane] = on ? (int)L.misc[24 + lane] : 0;
+                P.leaf[14 + lane] = on ? (int)L.misc[32 + lane] : 0;
+                P.eval_obs[lane] = on ? (int)L.misc[24 + lane] : 0;
             }
         }
         if (lane == 0) P.gs[TM_GS_N_EXPAND] += 1;
@@ -756,6 +767,7 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     if (lane == 0) {
         P.gs[TM_GS_CYC_SELECT] = (int)(tc_sel - tc_start);
         P.gs[TM_GS_CYC_EXPAND] = (int)(tc_exp - tc_sel);
+        P.gs[TM_GS_CYC_TAIL] = (int)cyc_mem;   // of CYC_SELECT: waiting for each level's statistics
         P.gs[TM_GS_TRACE_LEN] = len;
         P.gs[TM_GS_PENDING] = 1;
         P.gs[TM_GS_LEAF] = leaf;
@@ -807,9 +819,9 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
         uint32_t cs[7];
         if (i < tail) {
             int node = queue[i];
-            bit_test_set(omark, P.rec[(size_t)node * TM_REC_DW + 1]);
+            bit_test_set(omark, P.rec[(size_t)node * TM_REC_DW + TM_REC_OBS]);
             for (int a = 0; a < 7; ++a) {
-                uint32_t c = P.rec[(size_t)node * TM_REC_DW + 3 + a];
+                uint32_t c = P.kids[(size_t)node * TM_KIDS_DW + a];
                 if (!bit_test_set(nmark, c)) cs[cnt++] = c;
             }
         }
@@ -871,9 +883,12 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
         if (j < nfree) {
             int i = P.fnode[j];
             uint4* r = reinterpret_cast<uint4*>(P.rec + (size_t)i * TM_REC_DW);
-            uint32_t keep_o = P.rec[(size_t)i * TM_REC_DW + 1];   // node_to_obs is not reset by the reference
+            uint32_t keep_o = P.rec[(size_t)i * TM_REC_DW + TM_REC_OBS];   // node_to_obs is not reset by the reference
             for (int t = 0; t < TM_REC_DW / 4; ++t) r[t] = make_uint4(0, 0, 0, 0);
-            P.rec[(size_t)i * TM_REC_DW + 1] = keep_o;
+            P.rec[(size_t)i * TM_REC_DW + TM_REC_OBS] = keep_o;
+            uint4* kd = reinterpret_cast<uint4*>(P.kids + (size_t)i * TM_KIDS_DW);
+            kd[0] = make_uint4(0, 0, 0, 0);
+            kd[1] = make_uint4(0, 0, 0, 0);
         }
     }
     for (int base = 0; base < onfree; base += 64) {
@@ -979,15 +994,16 @@ __global__ void k_root_stats(tm_store S, float* stats, int32_t* action) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= S.n_games) return;
     GP P = game_ptrs(S, g);
-    const uint32_t* r = P.rec + (size_t)P.gs[TM_GS_ROOT] * TM_REC_DW;
-    float self = __uint_as_float(r[2]);
+    const int root = P.gs[TM_GS_ROOT];
+    float self = __uint_as_float(P.rec[(size_t)root * TM_REC_DW + TM_REC_SCORE]);
     float* out = stats + (size_t)g * 21;
     const bool cpp = (S.kind == TM_KIND_CPPAGENT_LP || S.kind == TM_KIND_CPPAGENT);
     int best = 0, first_nan = -1;
     float bestv = 0;
     for (int a = 0; a < 7; ++a) {
-        uint32_t o = r[10 + a];
-        float sc = __uint_as_float(r[17 + a]);
+        const uint32_t c = P.kids[(size_t)root * TM_KIDS_DW + a];    // child 0 = null node: record all zero
+        const uint32_t o = P.rec[(size_t)c * TM_REC_DW + TM_REC_OBS];
+        const float sc = __uint_as_float(P.rec[(size_t)c * TM_REC_DW + TM_REC_SCORE]);
         uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
         float value = __uint_as_float(st.y);
         float v1;
@@ -1031,6 +1047,8 @@ __global__ void k_pool_reset(tm_store S, const uint8_t* mask) {
     const uint4 z = make_uint4(0, 0, 0, 0);
     uint4* rec = reinterpret_cast<uint4*>(P.rec);
     for (size_t i = threadIdx.x; i < (size_t)N * TM_REC_DW / 4; i += blockDim.x) rec[i] = z;
+    uint4* kd = reinterpret_cast<uint4*>(P.kids);
+    for (size_t i = threadIdx.x; i < (size_t)N * TM_KIDS_DW / 4; i += blockDim.x) kd[i] = z;
     uint4* gm = reinterpret_cast<uint4*>(P.game);
     for (size_t i = threadIdx.x; i < (size_t)N * GAME_DW / 4; i += blockDim.x) gm[i] = z;
     uint4* stt = reinterpret_cast<uint4*>(P.stat);
@@ -1131,9 +1149,9 @@ __global__ void k_export_game(tm_store S, int g, int32_t* child, float* score, i
     if (i >= S.max_nodes) return;
     GP P = game_ptrs(S, g);
     const uint32_t* r = P.rec + (size_t)i * TM_REC_DW;
-    for (int a = 0; a < 7; ++a) child[(size_t)i * 7 + a] = (int)r[3 + a];
-    score[i] = __uint_as_float(r[2]);
-    n_to_o[i] = (int)r[1];
+    for (int a = 0; a < 7; ++a) child[(size_t)i * 7 + a] = (int)P.kids[(size_t)i * TM_KIDS_DW + a];
+    score[i] = __uint_as_float(r[TM_REC_SCORE]);
+    n_to_o[i] = (int)r[TM_REC_OBS];
     uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)i * 4);
     visit[i] = (int)st.x;
     value[i] = __uint_as_float(st.y);
@@ -1222,7 +1240,8 @@ int tm_export_game(const tm_store* s, int game, int32_t* child, float* score, in
 // layout self-description so the host mirror (ctypes) can be checked without a GPU
 extern "C" int tm_store_layout(int* out, int n) {
     int v[] = {(int)sizeof(tm_store), (int)offsetof(tm_store, gamma), (int)offsetof(tm_store, node_rec),
-               (int)offsetof(tm_store, nq_table), (int)offsetof(tm_store, replay_count), (int)offsetof(tm_store, mt_state)};
+               (int)offsetof(tm_store, nq_table), (int)offsetof(tm_store, replay_count), (int)offsetof(tm_store, mt_state),
+               (int)offsetof(tm_store, node_child)};
     int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < m; ++i) out[i] = v[i];
     return m;

@@ -14,7 +14,7 @@ SIM_BACKUP, SIM_FRONT = 1, 2
 KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA = 0, 1, 2, 3, 4
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18,
-          CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22)
+          CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_SELECT_MEM=23)
 
 _nq_cache = {}
 
@@ -62,7 +62,7 @@ class TreeStore:
         z = lambda *shape, dtype=torch.int32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         bm = ((N + 7) // 8 + 15) & ~15
         self.t = dict(
-            node_rec=z(G, N, 24), node_game=z(G, N, 16), obs_stat=z(G, N, 4), obs_key=z(G, N, 12),
+            node_rec=z(G, N, 24), node_child=z(G, N, 8), node_game=z(G, N, 16), obs_stat=z(G, N, 4), obs_key=z(G, N, 12),
             node_tab=z(G, cap, dtype=torch.int64), obs_tab=z(G, cap, dtype=torch.int64),
             free_node=z(G, N), free_obs=z(G, N), gs=z(G, 32), rng=z(G, 32), env_game=z(G, 16), env_line_stats=z(G, 4),
             trace=z(G, max_trace, 4), leaf=z(G, 32), eval_obs=z(G * eval_slots),
