@@ -224,13 +224,13 @@ def main():
         nn_roof = {"kernel": "value net forward (tm_valuenet_forward + eval render), per launch of %d states" % (Gs * K),
                    "bound": "mfma", "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                    "frac": a_tf / PEAK_F32_MATRIX_TFLOPS,
-                   "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1", "tmcts_vn::k_vn_fcout"], 2.0)
+                   "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1", "tmcts_vn::k_fc_out"], 2.0)
                    if args.backend == "hip" else None,
                    "traffic_note": "bytes/launch, FETCH_SIZE x2 (wide streams) + WRITE_SIZE from profiles/r01_pmc_traffic.json",
                    "avg_launch_ms": nn_ms}
         tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % Gs, "bound": "hbm",
                      "achieved": a_gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBPS,
-                     "traffic": pmc_traffic(["tmcts::k_sim_step"]),
+                     "traffic": pmc_traffic(["tmcts::k_sim_step<false>"]),
                      "traffic_note": "bytes/launch of 4096 games at mean trace length ~20 (move 1), FETCH_SIZE + WRITE_SIZE "
                                      "from profiles/r01_pmc_traffic.json (narrow scattered accesses: no gfx950 correction)",
                      "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps}
