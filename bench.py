@@ -212,7 +212,7 @@ def main():
         "error_games": int(err),
         "store_gib_per_gpu": sum(S.nbytes() for S in stores) / 2**30,
         "last_sim_phase_kcycles": {k: float(np.mean([S.t["gs"][:, st.GS[k]].float().mean().item() for S in stores])) / 1e3
-                                   for k in ("CYC_BACK", "CYC_SELECT", "CYC_SELECT_MEM", "CYC_EXPAND", "TRACE_LEN")},
+                                   for k in ("CYC_BACK", "CYC_SELECT", "CYC_EXPAND", "TRACE_LEN")},
     }
     if not args.graph and n_nn:
         nn_ms, tree_ms = t_nn / n_nn, t_tree / n_tree

@@ -102,9 +102,6 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
 __device__ __forceinline__ uint64_t rl_u64(uint64_t v, int src) {   // wave-uniform source lane
     return ((uint64_t)rl_u32((uint32_t)(v >> 32), src) << 32) | rl_u32((uint32_t)v, src);
 }
-__device__ __forceinline__ double shfl_f64(double v, int src) {
-    return __longlong_as_double((long long)shfl_u64((uint64_t)__double_as_longlong(v), src));
-}
 
 // ---------------------------------------------------------------------------------------------------
 // glibc rand() (TYPE_3, r[i] = r[i-3] + r[i-31]; core.h:62,76 call the process-global generator, here
@@ -456,7 +453,6 @@ __device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lan
         int i = len - 1 - base - lane;
         uint4 e = make_uint4(0, 0, 0, 0);
         if (lane < cnt) e = reinterpret_cast<const uint4*>(P.trace)[i];
-        float sc = __uint_as_float(e.z);
         double x = 0;
         float xf = 0;
         for (int j = 0; j < cnt; ++j) {
@@ -473,7 +469,6 @@ __device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lan
                 V = t + (double)sj;
             }
         }
-        (void)sc;
         if (lane < cnt) {
             uint32_t* st = P.stat + (size_t)e.y * 4;
             if (float_carry) welford_f32carry(st, xf, varf);
@@ -506,7 +501,7 @@ __device__ inline void lane_backup_trace_seq(const tm_store& S, const GP& P, int
     }
 }
 
-__device__ inline bool trace_has_repeat(const GP& P, WaveLds& L, int lane, int len, const int* extra, int n_extra) {
+__device__ inline bool trace_has_repeat(const GP& P, int lane, int len, const int* extra, int n_extra) {
     // O(len^2/64) comparison of observation indices; only called when app > 1
     bool rep = false;
     for (int base = 0; base < len; base += 64) {
@@ -519,7 +514,6 @@ __device__ inline bool trace_has_repeat(const GP& P, WaveLds& L, int lane, int l
         for (int j = 0; j < n_extra; ++j)
             if (i < len && (uint32_t)extra[j] == oi) rep = true;
     }
-    (void)L;
     return __any(rep);
 }
 
@@ -534,8 +528,6 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
     const int kind = S.kind;
     const bool fcarry = (kind == TM_KIND_CPPAGENT_LP || kind == TM_KIND_CPPAGENT);
     double v0 = 0, var0 = 0;
-    int c_obs[1];
-    int n_extra = 0;
     bool seq = false;
     if (kind == TM_KIND_VANILLA) {
         v0 = (double)leaf_score;   // the rollout's final score (or the terminal leaf's own), Vanilla.py:54,59
@@ -549,7 +541,7 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
         else v0 = (double)ls;
     } else {
         // leaf-parallel: first-visit initialisation of the unique children, then the averaged target
-        if (S.app > 1) seq = trace_has_repeat(P, L, lane, len, P.leaf + 7, k);
+        if (S.app > 1) seq = trace_has_repeat(P, lane, len, P.leaf + 7, k);
         if (k > 0) {
             int co = (lane < k) ? P.leaf[7 + lane] : 0;
             float cs = (lane < k) ? __int_as_float(P.leaf[14 + lane]) : 0.f;
@@ -588,7 +580,7 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
         __threadfence_block();
     }
     if (S.app > 1 && kind != TM_KIND_VALUESIM_LP && kind != TM_KIND_CPPAGENT_LP)
-        seq = trace_has_repeat(P, L, lane, len, c_obs, n_extra);
+        seq = trace_has_repeat(P, lane, len, nullptr, 0);
     if (seq) { if (lane == 0) lane_backup_trace_seq(S, P, len, v0, var0, fcarry); }
     else wave_backup_trace(S, P, lane, len, v0, var0, fcarry);
     if (lane == 0) { P.gs[TM_GS_PENDING] = 0; P.gs[TM_GS_N_SIMS] += 1; }
@@ -618,7 +610,6 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     // would make every level wait for its acknowledgement); the trace goes through LDS and is flushed 64 entries at
     // a time with coalesced 16-byte stores.
     const int pf_t = lane >> 3, pf_k = lane & 7;
-    long long cyc_mem = 0;
     uint32_t dx = 0, dy = 0, dz = 0;
     if (lane < 8) {
         const uint32_t* p = P.rec + (size_t)idx * TM_REC_DW + 3 * lane;
@@ -646,7 +637,6 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         const uint32_t c = on ? dx : 0u, o = on ? dy : 0u;     // empty slots / other lanes read entry 0 (always valid)
         const float sc = __uint_as_float(dz);
         // loads of this level: statistics of my child observation; piece pf_k of unique child pf_t
-        const long long tm_a = __builtin_readcyclecounter();
         const uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
         uint32_t ct = shfl_u32(c, pf_t < 7 ? pf_t : 0);
         ct = (pf_t < nu) ? ct : 0u;
@@ -654,7 +644,6 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         const uint32_t px = pp[0], py = pp[1], pz = pp[2];
         const int visit = on ? (int)st.x : 0;
         const uint64_t lowmask = __ballot(on && visit < low);
-        cyc_mem += __builtin_readcyclecounter() - tm_a;      // issue of the level's loads -> statistics available
         int sel;
         if (lowmask) {
             // check_low (core.h:65-77): a uniformly drawn under-visited child, libc rand()
@@ -767,7 +756,6 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     if (lane == 0) {
         P.gs[TM_GS_CYC_SELECT] = (int)(tc_sel - tc_start);
         P.gs[TM_GS_CYC_EXPAND] = (int)(tc_exp - tc_sel);
-        P.gs[TM_GS_CYC_TAIL] = (int)cyc_mem;   // of CYC_SELECT: waiting for each level's statistics
         P.gs[TM_GS_TRACE_LEN] = len;
         P.gs[TM_GS_PENDING] = 1;
         P.gs[TM_GS_LEAF] = leaf;
