@@ -44,7 +44,9 @@ enum {
     TM_GS_TRACE_SUM, /* sum of trace lengths over all simulations (for bytes/simulation accounting) */
     TM_GS_N_EVAL,    /* leaf states handed to the evaluator */
     TM_GS_N_POOL_RESET, /* tm_pool_reset calls that hit this game */
-    TM_GS_CYC_BACK = 20, TM_GS_CYC_SELECT, TM_GS_CYC_EXPAND, TM_GS_CYC_TAIL  /* shader cycles of the last simulation's phases */
+    TM_GS_CYC_BACK = 20, TM_GS_CYC_SELECT, TM_GS_CYC_EXPAND, /* shader cycles of the last simulation's phases */
+    TM_GS_CYC_TAIL,      /* duration of the last GC in units of 16 cycles; +1: nodes reachable at that GC */
+    TM_GS_LOW_NODE = 26, TM_GS_LOW_OBS   /* lowest node / observation index ever allocated (GC skips untouched entries) */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */

@@ -242,7 +242,12 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     }
     int idx = found;
     if (isnew) idx = P.fnode[nfree - 1 - __popcll(need & ((1ull << lane) - 1ull))];
-    if (lane == 0 && cnt) P.gs[TM_GS_NFREE_NODE] = nfree - cnt;
+    if (cnt) {
+        // lowest index ever allocated (GC skips clearing what was never written)
+        int lo = 0x7FFFFFFF;
+        for (int b = 0; b < n; ++b) lo = min(lo, ((need >> b) & 1ull) ? (int)rl_u32((uint32_t)idx, b) : 0x7FFFFFFF);
+        if (lane == 0) { P.gs[TM_GS_NFREE_NODE] = nfree - cnt; if (lo < P.gs[TM_GS_LOW_NODE]) P.gs[TM_GS_LOW_NODE] = lo; }
+    }
     table_insert_seq(P.ntab, mask, need, n, lane, h, ins, idx, L.misc);
     // 3. observations of the new nodes (agents/agent.py:112-128)
     uint32_t* ok = L.okeys[act ? lane : 0];
@@ -266,7 +271,11 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     int onfree = P.gs[TM_GS_NFREE_OBS];
     int o = ofound;
     if (onew) o = P.fobs[onfree - 1 - __popcll(oneed & ((1ull << lane) - 1ull))];
-    if (lane == 0 && ocnt) P.gs[TM_GS_NFREE_OBS] = onfree - ocnt;
+    if (ocnt) {
+        int lo = 0x7FFFFFFF;
+        for (int b = 0; b < n; ++b) lo = min(lo, ((oneed >> b) & 1ull) ? (int)rl_u32((uint32_t)o, b) : 0x7FFFFFFF);
+        if (lane == 0) { P.gs[TM_GS_NFREE_OBS] = onfree - ocnt; if (lo < P.gs[TM_GS_LOW_OBS]) P.gs[TM_GS_LOW_OBS] = lo; }
+    }
     table_insert_seq(P.otab, mask, oneed, n, lane, ho, oins, o, L.misc + 8);
     if (onew) {
         uint4* dst = reinterpret_cast<uint4*>(P.okey + (size_t)o * OBS_DW);
@@ -788,6 +797,7 @@ __device__ __forceinline__ bool bit_test(const uint8_t* bm, uint32_t i) {
 }
 
 __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane) {
+    const long long gc_t0 = __builtin_readcyclecounter();
     const int N = S.max_nodes;
     const size_t bm_bytes = (((size_t)N + 7) / 8 + 15) & ~(size_t)15;
     uint8_t* nmark = S.gc_mark + (size_t)g * 2 * bm_bytes;
@@ -806,12 +816,21 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
         int cnt = 0;
         uint32_t cs[7];
         if (i < tail) {
-            int node = queue[i];
-            bit_test_set(omark, P.rec[(size_t)node * TM_REC_DW + TM_REC_OBS]);
-            for (int a = 0; a < 7; ++a) {
-                uint32_t c = P.kids[(size_t)node * TM_KIDS_DW + a];
-                if (!bit_test_set(nmark, c)) cs[cnt++] = c;
-            }
+            const int node = queue[i];
+            // all loads of the round first, then all seven test-and-set atomics back to back (their latencies overlap),
+            // then the results: a round costs one atomic round trip instead of seven
+            const uint4 k0 = *reinterpret_cast<const uint4*>(P.kids + (size_t)node * TM_KIDS_DW);
+            const uint4 k1 = *reinterpret_cast<const uint4*>(P.kids + (size_t)node * TM_KIDS_DW + 4);
+            const uint32_t ob = P.rec[(size_t)node * TM_REC_DW + TM_REC_OBS];
+            const uint32_t ch[7] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z};
+            uint32_t old[7];
+#pragma unroll
+            for (int a = 0; a < 7; ++a)
+                old[a] = atomicOr(reinterpret_cast<uint32_t*>(nmark) + (ch[a] >> 5), 1u << (ch[a] & 31));
+            atomicOr(reinterpret_cast<uint32_t*>(omark) + (ob >> 5), 1u << (ob & 31));
+#pragma unroll
+            for (int a = 0; a < 7; ++a)
+                if (!((old[a] >> (ch[a] & 31)) & 1u)) cs[cnt++] = ch[a];
         }
         head = min(tail, head + 64);
         // append this round's discoveries: exclusive scan of cnt over the wave
@@ -830,67 +849,139 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
     }
     // the root of an unexpanded tree still reaches node 0 through its zero child row
     __threadfence();
-    // free lists, ascending (agents/agent.py:211-212,221-222)
-    int nfree = 0, onfree = 0;
-    for (int base = 0; base < N; base += 64) {
-        int i = base + lane;
-        bool fr = (i < N) && !bit_test(nmark, (uint32_t)i);
-        uint64_t bm = __ballot(fr);
-        if (fr) P.fnode[nfree + __popcll(bm & ((1ull << lane) - 1ull))] = i;
-        nfree += __popcll(bm);
-        bool ofr = (i < N) && !bit_test(omark, (uint32_t)i);
-        uint64_t obm = __ballot(ofr);
-        if (ofr) P.fobs[onfree + __popcll(obm & ((1ull << lane) - 1ull))] = i;
-        onfree += __popcll(obm);
-    }
-    __threadfence();
-    // harvest replay tuples from the freed observations, ascending (ValueSim.py:122-159)
-    if (S.online && S.replay_cap > 0) {
-        int m = S.replay_count[g];
-        for (int base = 0; base < onfree; base += 64) {
-            int j = base + lane;
-            int o = (j < onfree) ? P.fobs[j] : 0;
-            uint4 st = make_uint4(0, 0, 0, 0);
-            if (j < onfree) st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
-            bool keep = (j < onfree) && ((int)st.x >= S.min_visits_to_store) && !(st.w & 1u);
-            uint64_t bm = __ballot(keep);
-            int pos = m + __popcll(bm & ((1ull << lane) - 1ull));
-            if (keep && pos < S.replay_cap) {
-                uint32_t* dk = S.replay_obs + ((size_t)g * S.replay_cap + pos) * TM_OBS_DW;
-                for (int t = 0; t < TM_OBS_DW; ++t) dk[t] = P.okey[(size_t)o * TM_OBS_DW + t];
-                float* ds = S.replay_stat + ((size_t)g * S.replay_cap + pos) * 4;
-                ds[0] = __uint_as_float(st.y); ds[1] = __uint_as_float(st.z); ds[2] = (float)(int)st.x; ds[3] = 0.f;
-            }
-            m = min(S.replay_cap, m + __popcll(bm));
-        }
-        if (lane == 0) S.replay_count[g] = m;
-    }
-    // reset_arrays (agents/agent.py:227-244): clear what was freed
-    for (int base = 0; base < nfree; base += 64) {
-        int j = base + lane;
-        if (j < nfree) {
-            int i = P.fnode[j];
-            uint4* r = reinterpret_cast<uint4*>(P.rec + (size_t)i * TM_REC_DW);
-            uint32_t keep_o = P.rec[(size_t)i * TM_REC_DW + TM_REC_OBS];   // node_to_obs is not reset by the reference
-            for (int t = 0; t < TM_REC_DW / 4; ++t) r[t] = make_uint4(0, 0, 0, 0);
-            P.rec[(size_t)i * TM_REC_DW + TM_REC_OBS] = keep_o;
-            uint4* kd = reinterpret_cast<uint4*>(P.kids + (size_t)i * TM_KIDS_DW);
-            kd[0] = make_uint4(0, 0, 0, 0);
-            kd[1] = make_uint4(0, 0, 0, 0);
-        }
-    }
-    for (int base = 0; base < onfree; base += 64) {
-        int j = base + lane;
-        if (j < onfree) {
-            int o = P.fobs[j];
-            *reinterpret_cast<uint4*>(P.stat + (size_t)o * 4) = make_uint4(0, 0, 0, 0);
-            uint4* k4 = reinterpret_cast<uint4*>(P.okey + (size_t)o * TM_OBS_DW);
-            k4[0] = k4[1] = k4[2] = make_uint4(0, 0, 0, 0);
-        }
-    }
-    // rebuild both tables from what is kept
+    // both tables are rebuilt from what is kept: clear them first (nothing below reads them)
     for (size_t i = lane; i < (size_t)S.table_cap; i += 64) { P.ntab[i] = 0; P.otab[i] = 0; }
     __threadfence();
+    // Sweeps over the pool: each lane takes one 32-bit word of a bitmap = 32 consecutive indices per pass (2048 per
+    // wave pass), so a 100 000-entry pool is 49 passes instead of 1563 dependent ones.  Free lists come out ascending
+    // (agents/agent.py:211-212,221-222): lane-major order is index order, positions from a wave prefix sum.  Freed
+    // records are cleared by store-only streams (reset_arrays, agent.py:227-244); indices below the lowest index ever
+    // allocated were never written and are skipped.
+    const int n_words = (N + 31) / 32;
+    const uint32_t* nw = reinterpret_cast<const uint32_t*>(nmark);
+    const uint32_t* ow = reinterpret_cast<const uint32_t*>(omark);
+    const int low_node = P.gs[TM_GS_LOW_NODE], low_obs = P.gs[TM_GS_LOW_OBS];
+    const bool harvest = S.online && S.replay_cap > 0;
+    int nfree = 0, onfree = 0;
+    int m = harvest ? S.replay_count[g] : 0;
+    auto wave_scan = [&](int v, int& total) {   // inclusive prefix sum over the wave
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        total = __shfl(incl, 63, 64);
+        return incl;
+    };
+    for (int wbase = 0; wbase < n_words; wbase += 64) {
+        const int wi = wbase + lane;
+        uint32_t valid = 0;
+        if (wi < n_words) { int rem = N - wi * 32; valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u); }
+        // ---- nodes ----
+        const uint32_t fr = (wi < n_words) ? (~nw[wi] & valid) : 0u;
+        int total;
+        int pos = nfree + wave_scan(__popc(fr), total) - __popc(fr);
+        // words that are entirely free (the common case: freed indices come in long runs) are cleared by the whole
+        // wave with contiguous 16-byte stores; only partially free words fall back to per-lane scattered stores.
+        // (A freed node's node_to_obs is cleared too: the reference leaves it stale, agents/agent.py:234-235, but
+        // nothing ever reads it before new_node overwrites it.)
+        const bool nfull = (wi < n_words) && valid == 0xFFFFFFFFu && fr == 0xFFFFFFFFu && (wi * 32 >= low_node);
+        for (uint64_t fm = __ballot(nfull); fm; fm &= fm - 1) {
+            const int w0 = (wbase + (__ffsll((long long)fm) - 1)) * 32;     // first node of a fully free word
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            uint4* r = reinterpret_cast<uint4*>(P.rec + (size_t)w0 * TM_REC_DW);       // 32 x 96 B = 192 uint4
+            r[lane] = z; r[64 + lane] = z; r[128 + lane] = z;
+            reinterpret_cast<uint4*>(P.kids + (size_t)w0 * TM_KIDS_DW)[lane] = z;      // 32 x 32 B = 64 uint4
+        }
+        for (uint32_t bits = fr; bits; bits &= bits - 1) {
+            const int i = wi * 32 + (__ffs(bits) - 1);
+            P.fnode[pos++] = i;
+            if (i >= low_node && !nfull) {
+                uint4* r = reinterpret_cast<uint4*>(P.rec + (size_t)i * TM_REC_DW);
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                r[0] = z; r[1] = z; r[2] = z; r[3] = z; r[4] = z;
+                uint32_t* rr = P.rec + (size_t)i * TM_REC_DW;
+                rr[20] = 0; rr[TM_REC_HDR] = 0; rr[TM_REC_SCORE] = 0;     // TM_REC_OBS (node_to_obs) is not reset by the reference
+                uint4* kd = reinterpret_cast<uint4*>(P.kids + (size_t)i * TM_KIDS_DW);
+                kd[0] = z; kd[1] = z;
+            }
+        }
+        nfree += total;
+        // ---- observations ----
+        const uint32_t ofr = (wi < n_words) ? (~ow[wi] & valid) : 0u;
+        int ototal;
+        int opos = onfree + wave_scan(__popc(ofr), ototal) - __popc(ofr);
+        uint32_t keepmask = 0;
+        if (harvest) {
+            // store_nodes (ValueSim.py:122-159): freed observations with enough visits that are not terminal
+            for (uint32_t bits = ofr; bits;) {
+                int ob[4];
+                uint4 st4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ob[u] = bits ? (__ffs(bits) - 1) : -1;
+                    bits &= bits ? bits - 1 : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int o = wi * 32 + (ob[u] < 0 ? 0 : ob[u]);
+                    st4[u] = (ob[u] >= 0 && o >= low_obs) ? *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4) : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ob[u] >= 0 && (int)st4[u].x >= S.min_visits_to_store && !(st4[u].w & 1u)) keepmask |= 1u << ob[u];
+            }
+            int ktotal;
+            int kpos = m + wave_scan(__popc(keepmask), ktotal) - __popc(keepmask);
+            for (uint32_t bits = keepmask; bits; bits &= bits - 1) {
+                const int o = wi * 32 + (__ffs(bits) - 1);
+                if (kpos < S.replay_cap) {
+                    const uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
+                    const uint4* sk = reinterpret_cast<const uint4*>(P.okey + (size_t)o * TM_OBS_DW);
+                    uint4* dk = reinterpret_cast<uint4*>(S.replay_obs + ((size_t)g * S.replay_cap + kpos) * TM_OBS_DW);
+                    dk[0] = sk[0]; dk[1] = sk[1]; dk[2] = sk[2];
+                    float* ds = S.replay_stat + ((size_t)g * S.replay_cap + kpos) * 4;
+                    ds[0] = __uint_as_float(st.y); ds[1] = __uint_as_float(st.z); ds[2] = (float)(int)st.x; ds[3] = 0.f;
+                }
+                kpos += 1;
+            }
+            m = min(S.replay_cap, m + ktotal);
+        }
+        for (uint32_t bits = (wi < n_words) ? (ow[wi] & valid) : 0u; bits; bits &= bits - 1) {
+            const int o = wi * 32 + (__ffs(bits) - 1);     // kept observation: back into the (cleared) table
+            if (o == 0) continue;
+            uint32_t key[OBS_DW];
+            const uint4* src = reinterpret_cast<const uint4*>(P.okey + (size_t)o * OBS_DW);
+            for (int t = 0; t < 3; ++t) { uint4 v = src[t]; key[4*t] = v.x; key[4*t+1] = v.y; key[4*t+2] = v.z; key[4*t+3] = v.w; }
+            const uint64_t h = hash_obs(key);
+            uint32_t sl = (uint32_t)h & mask;
+            const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)o;
+            while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.otab[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
+        }
+        const bool ofull = (wi < n_words) && valid == 0xFFFFFFFFu && ofr == 0xFFFFFFFFu && (wi * 32 >= low_obs);
+        for (uint64_t fm = __ballot(ofull); fm; fm &= fm - 1) {
+            const int w0 = (wbase + (__ffsll((long long)fm) - 1)) * 32;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            if (lane < 32) reinterpret_cast<uint4*>(P.stat + (size_t)w0 * 4)[lane] = z;            // 32 x 16 B
+            uint4* k4 = reinterpret_cast<uint4*>(P.okey + (size_t)w0 * TM_OBS_DW);                 // 32 x 48 B = 96 uint4
+            k4[lane] = z;
+            if (lane < 32) k4[64 + lane] = z;
+        }
+        for (uint32_t bits = ofr; bits; bits &= bits - 1) {
+            const int o = wi * 32 + (__ffs(bits) - 1);
+            P.fobs[opos++] = o;
+            if (o >= low_obs && !ofull) {
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(P.stat + (size_t)o * 4) = z;
+                uint4* k4 = reinterpret_cast<uint4*>(P.okey + (size_t)o * TM_OBS_DW);
+                k4[0] = z; k4[1] = z; k4[2] = z;
+            }
+        }
+        onfree += ototal;
+    }
+    if (harvest && lane == 0) S.replay_count[g] = m;
+    __threadfence();
+    // re-insert the kept nodes (the BFS queue lists them)
     // parallel reinsertion: lanes claim empty slots with a 64-bit compare-and-swap (no deletions happen
     // concurrently, so linear probing stays consistent; placement order does not affect lookups)
     for (int base = 0; base < tail; base += 64) {
@@ -906,22 +997,12 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
             while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.ntab[s]), 0ull, ent) != 0ull) s = (s + 1) & mask;
         }
     }
-    for (int base = 0; base < N; base += 64) {
-        int o = base + lane;
-        if (o >= 1 && o < N && bit_test(omark, (uint32_t)o)) {
-            uint32_t key[OBS_DW];
-            const uint4* src = reinterpret_cast<const uint4*>(P.okey + (size_t)o * OBS_DW);
-            for (int t = 0; t < 3; ++t) { uint4 v = src[t]; key[4*t] = v.x; key[4*t+1] = v.y; key[4*t+2] = v.z; key[4*t+3] = v.w; }
-            uint64_t h = hash_obs(key);
-            uint32_t s = (uint32_t)h & mask;
-            unsigned long long ent = ((h >> 32) << 32) | (uint32_t)o;
-            while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.otab[s]), 0ull, ent) != 0ull) s = (s + 1) & mask;
-        }
-    }
     if (lane == 0) {
         P.gs[TM_GS_NFREE_NODE] = nfree;
         P.gs[TM_GS_NFREE_OBS] = onfree;
         P.gs[TM_GS_N_GC] += 1;
+        P.gs[TM_GS_CYC_TAIL] = (int)((__builtin_readcyclecounter() - gc_t0) >> 4);   // last GC, in units of 16 cycles
+        P.gs[TM_GS_CYC_TAIL + 1] = tail;                                                // reachable nodes at the last GC
     }
     __threadfence();
     (void)L;
@@ -1016,6 +1097,8 @@ __global__ void k_pool_init(tm_store S) {
         for (int i = 0; i < TM_GS_DW; ++i) P.gs[i] = 0;
         P.gs[TM_GS_NFREE_NODE] = N - 1;
         P.gs[TM_GS_NFREE_OBS] = N - 1;
+        P.gs[TM_GS_LOW_NODE] = N;
+        P.gs[TM_GS_LOW_OBS] = N;
         uint32_t r[32];
         int pos;
         srand_state(r, pos, 1u);   // the reference never calls srand(): glibc's default seed
@@ -1049,6 +1132,8 @@ __global__ void k_pool_reset(tm_store S, const uint8_t* mask) {
         P.gs[TM_GS_ROOT] = 0;
         P.gs[TM_GS_NFREE_NODE] = N - 1;
         P.gs[TM_GS_NFREE_OBS] = N - 1;
+        P.gs[TM_GS_LOW_NODE] = N;
+        P.gs[TM_GS_LOW_OBS] = N;
         P.gs[TM_GS_TRACE_LEN] = 0;
         P.gs[TM_GS_PENDING] = 0;
         P.gs[TM_GS_ERR] &= ~TM_ERR_POOL;
