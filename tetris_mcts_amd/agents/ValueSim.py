@@ -21,7 +21,6 @@ class ValueSim(TreeAgent):
         self.online = online
         self.n_trains = 0
         self._memory = None       # (packed observations, stats) carried over between trainings
-        kwargs_cap = memory_size
         self.memory_size = memory_size
         self.memory_growth_rate = memory_growth_rate
         self.min_visits_to_store = min_visits_to_store
