@@ -123,11 +123,12 @@ __global__ void k_vn_prepare(const float* __restrict__ P, float* __restrict__ pr
         int k = 2 * s + (l >> 5), row = l & 31;
         prep[t] = W[row * 288 + k];
     } else if (t < PREP_TOTAL) {
+        // fc1 runs on v_mfma_f32_16x16x4_f32: lane l supplies A[row = l&15][k = 4s + (l>>4)] for step s of a 16-row tile
         int e = t - 18432;
-        int ht = e / (224 * 256), e2 = e % (224 * 256);
+        int ht = e / (112 * 256), e2 = e % (112 * 256);
         int q = e2 / 256, l = (e2 / 4) % 64, r = e2 % 4;
         int s = 4 * q + r;
-        int k = 2 * s + (l >> 5), row = 32 * ht + (l & 31);
+        int k = 4 * s + (l >> 4), row = 16 * ht + (l & 15);
         prep[t] = P[OFF_F1W + (size_t)row * A3 + k];
     }
 }
@@ -339,39 +340,42 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
     }
 }
 
-// fc1 (1792 -> 256) + ReLU: a workgroup owns 32 states x 128 hidden units (one 32x32 accumulator per wave).
-constexpr int FC_KC = 128, FC_PITCH = FC_KC + 1;
-__global__ __launch_bounds__(256) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
+// fc1 (1792 -> 256) + ReLU on v_mfma_f32_16x16x4_f32 (D[16x16] += A[16x4] B[4x16]; lane l: A[i=l&15][k=l>>4],
+// B[k=l>>4][j=l&15], D[i=(l>>4)*4+r][j=l&15]; per output a k-ordered fma chain, 4 terms per instruction).
+// A workgroup of 8 waves owns 32 states x 128 hidden units: every wave a 16-row hidden tile and both 16-state
+// tiles (two independent accumulators), two waves per SIMD so one wave's LDS / L2 waits hide behind the other's
+// MFMAs.  Activations are staged through LDS in 128-wide K chunks, weight quads double-buffered in registers.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int FC_KC = 128, FC_PITCH = 132;
+__global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
                                                 float* __restrict__ hout, int hstride) {
     __shared__ float bt[2][32 * FC_PITCH];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, l15 = lane & 15;
     const int s0 = blockIdx.x * 32;
-    const int ht = blockIdx.y * 4 + w;   // hidden tile 0..7
-    const float4* W = reinterpret_cast<const float4*>(prep + PREP_W1) + (size_t)ht * 224 * 64 + lane;
-    f32x16 acc;
+    const int ht = blockIdx.y * 8 + w;   // 16-row hidden tile 0..15
+    const float4* W = reinterpret_cast<const float4*>(prep + PREP_W1) + (size_t)ht * 112 * 64 + lane;
+    f32x4 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = P[OFF_F1B + 32 * ht + (r & 3) + 8 * (r >> 2) + 4 * half];
-    // staging: 32 rows x 128 floats per chunk = 1024 float4, four per thread (rows row0 + 8 i)
+    for (int r = 0; r < 4; ++r) acc0[r] = acc1[r] = P[OFF_F1B + 16 * ht + kk * 4 + r];
+    // staging: 32 rows x 128 floats per chunk = 1024 float4, two per thread (rows row0, row0 + 16)
     const int row0 = threadIdx.x >> 5, c4 = (threadIdx.x & 31) * 4;
-    float4 st[4];
+    float4 st[2];
     auto gload = [&](int chunk) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int sa = s0 + row0 + 8 * i;
+        for (int i = 0; i < 2; ++i) {
+            int sa = s0 + row0 + 16 * i;
             st[i] = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4)
                              : make_float4(0, 0, 0, 0);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float* d = &bt[buf][(row0 + 8 * i) * FC_PITCH + c4];
-            d[0] = st[i].x; d[1] = st[i].y; d[2] = st[i].z; d[3] = st[i].w;
-        }
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<float4*>(&bt[buf][(row0 + 16 * i) * FC_PITCH + c4]) = st[i];
     };
-    constexpr int NCH = A3 / FC_KC;   // 14 chunks of 128 k = 64 MFMA steps = 16 weight quads
-    constexpr int QPC = FC_KC / 8;
+    constexpr int NCH = A3 / FC_KC;   // 14 chunks of 128 k = 32 MFMA steps = 8 weight quads
+    constexpr int QPC = FC_KC / 16;
     float4 wbuf[2][QPC];
     auto wload = [&](int chunk, int buf) {
 #pragma unroll
@@ -383,28 +387,34 @@ __global__ __launch_bounds__(256) void k_vn_fc1(const float* __restrict__ P, con
     __syncthreads();
 #pragma unroll 2
     for (int c = 0; c < NCH; ++c) {
-        // requests for the next chunk (activations -> registers, weights -> the other register buffer) go out first
         if (c + 1 < NCH) { gload(c + 1); wload(c + 1, (c + 1) & 1); }
-        const float* b = &bt[c & 1][l31 * FC_PITCH + half];
+        const float* b0 = &bt[c & 1][l15 * FC_PITCH + kk];
+        const float* b1 = &bt[c & 1][(16 + l15) * FC_PITCH + kk];
 #pragma unroll
         for (int q = 0; q < QPC; ++q) {
             const float4 w4 = wbuf[c & 1][q];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, b[2 * (4 * q + 0)], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, b[2 * (4 * q + 1)], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, b[2 * (4 * q + 2)], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, b[2 * (4 * q + 3)], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = (r == 0) ? w4.x : (r == 1) ? w4.y : (r == 2) ? w4.z : w4.w;
+                const int ks = 4 * (4 * q + r);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[ks], acc1, 0, 0, 0);
+            }
         }
         if (c + 1 < NCH) lstore((c + 1) & 1);
         __syncthreads();
     }
-    const int sj = s0 + l31;
-    if (sj < n) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int i = 32 * ht + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[r];
-            hout[(size_t)sj * hstride + i] = v > 0.0f ? v : 0.0f;
-        }
+    // D[i = kk*4 + r][j = l15]: four consecutive hidden units of one state per lane -> one 16-byte store
+    const int i0 = 16 * ht + kk * 4;
+    if (s0 + l15 < n) {
+        float4 o = make_float4(acc0[0] > 0.f ? acc0[0] : 0.f, acc0[1] > 0.f ? acc0[1] : 0.f, acc0[2] > 0.f ? acc0[2] : 0.f,
+                               acc0[3] > 0.f ? acc0[3] : 0.f);
+        *reinterpret_cast<float4*>(hout + (size_t)(s0 + l15) * hstride + i0) = o;
+    }
+    if (s0 + 16 + l15 < n) {
+        float4 o = make_float4(acc1[0] > 0.f ? acc1[0] : 0.f, acc1[1] > 0.f ? acc1[1] : 0.f, acc1[2] > 0.f ? acc1[2] : 0.f,
+                               acc1[3] > 0.f ? acc1[3] : 0.f);
+        *reinterpret_cast<float4*>(hout + (size_t)(s0 + 16 + l15) * hstride + i0) = o;
     }
 }
 
@@ -488,7 +498,7 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     if (blocks > 256) blocks = 256;   // one workgroup per CU, waves stride over the states
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, eval_obs,
                        eval_slots, max_nodes, n, scratch, SS);
-    hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(256), 0, stream, P, prepared, scratch, SS, n,
+    hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(512), 0, stream, P, prepared, scratch, SS, n,
                        scratch + A3, SS);
     hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, v, var, n);
     return (int)hipGetLastError();
