@@ -55,6 +55,7 @@ def lib():
             f = getattr(L, "orc_agent_" + name)
             f.restype, f.argtypes = C.c_long, [vp]
         L.orc_agent_set_mt.argtypes = [vp, vp]
+        L.orc_agent_set_cpp_occupied.argtypes = [vp, i32]
         L.orc_agent_n_rollout_steps.restype, L.orc_agent_n_rollout_steps.argtypes = C.c_long, [vp]
         L.orc_mt_randint7_test.argtypes = [vp]
         L.orc_game_init.argtypes = [vp, i32, i32, i32, u32]
@@ -132,7 +133,8 @@ class Agent:
     """Oracle tree agent. kind: 0 ValueSim, 1 ValueSimLP, 2 all-C++ agent LP, 3 all-C++ agent single, 4 Vanilla."""
 
     def __init__(self, kind, max_nodes=100000, app=1, scoring=0, randomizer=0, gamma=0.999, low=1, benchmark=False,
-                 online=False, min_visits_to_store=None, memory_size=0, evaluator="hash", params=None):
+                 online=False, min_visits_to_store=None, memory_size=0, evaluator="hash", params=None,
+                 cpp_occupied=False):
         L = lib()
         self.L = L
         if min_visits_to_store is None:
@@ -155,6 +157,11 @@ class Agent:
         self.max_nodes = max_nodes
         self.h = L.orc_agent_new(max_nodes, app, scoring, randomizer, kind, gamma, low, int(benchmark), int(online),
                                  min_visits_to_store, memory_size, fn, ctx)
+        if cpp_occupied:
+            # the reference C++ agent's `occupied` vector slip (agent.cpp:300-301, see agent_oracle.c); only where the
+            # oracle is compared with the reference's compiled agent, never where it checks the product
+            assert kind in (2, 3)
+            L.orc_agent_set_cpp_occupied(self.h, 1)
 
     def set_python_random_state(self, state):
         """state = random.getstate() (or random.Random(seed).getstate()): the rollout RNG of Vanilla (Vanilla.py:4,52)."""

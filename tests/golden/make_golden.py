@@ -294,8 +294,62 @@ def gen_cppagent():
         json.dump(out, f)
 
 
+def gen_online():
+    """The reference's OnlineMCTSAgent (agents/cppmodule/agent.cpp:569-816, compiled in place) with online=True:
+    every train() payload (memory contents at the moment the accumulation policy fires), for the four policies.
+    Small pool -> frequent GC; small memory -> policies 0/1 trim, policy 2 fires on a full memory."""
+    import hashlib
+    ref_shims.install()
+    from pyTetris import Tetris
+    agent_mod = sys.modules["agents.cppmodule.agent"]
+
+    def ev_lp(obs):
+        a = np.asarray(obs).astype(np.int8)
+        v, var = hash_eval(a.reshape(a.shape[0], 20, 10))
+        return [v.tolist(), var.tolist()]
+    out = []
+    cfgs = [dict(policy=0, memory_size=400, episodes_per_train=3, growth=100),
+            dict(policy=1, memory_size=400, episodes_per_train=3, growth=100),
+            dict(policy=2, memory_size=600, episodes_per_train=3, growth=100),
+            dict(policy=3, memory_size=2000, episodes_per_train=3, growth=300)]
+    for c in cfgs:
+        sims, max_nodes, min_visit, seed, moves = 30, 8000, 3, 41 + c["policy"], 900
+        calls, state = [], dict(move=0)
+
+        def train(m_state, m_value, m_variance, m_visit, size, calls=calls, state=state):
+            st = np.ascontiguousarray(np.asarray(m_state)[:size]).astype(np.int8)
+            val = np.ascontiguousarray(np.asarray(m_value)[:size], "<f4").reshape(-1)
+            var = np.ascontiguousarray(np.asarray(m_variance)[:size], "<f4").reshape(-1)
+            vis = np.ascontiguousarray(np.asarray(m_visit)[:size], "<f4").reshape(-1)
+            calls.append(dict(move=state["move"], size=int(size), states_sha1=hashlib.sha1(st.tobytes()).hexdigest(),
+                              value=val.tobytes().hex(), variance=var.tobytes().hex(), visit=vis.tobytes().hex()))
+        ref_shims.srand(1)
+        # agent.cpp:29's std::mt19937 mt(123) is process-wide and only policy 0 draws from it: policy 0 runs first
+        agent = agent_mod.OnlineMCTSAgent(sims, max_nodes, True, c["policy"], c["memory_size"], c["episodes_per_train"],
+                                          c["growth"], min_visit, True, 0.999, False, ev_lp, 0, train, True)
+        game = Tetris((20, 10), 1, 0, 0, seed)
+        agent.update_root(game)
+        rec, episodes = [], 0
+        for m in range(moves):
+            state["move"] = m
+            a = int(agent.play())
+            game.play(a)
+            agent.update_root(game)
+            rec.append(a)
+            if game.end:
+                episodes += 1
+                game.reset()
+                agent.update_root(game)
+        out.append(dict(c, sims=sims, max_nodes=max_nodes, min_visit=min_visit, seed=seed, actions=rec, train_calls=calls,
+                        episodes=episodes))
+        print("OnlineMCTSAgent policy %d: %d moves, %d episodes, %d train calls, sizes %s" % (
+            c["policy"], moves, episodes, len(calls), [k["size"] for k in calls][:12]), file=sys.stderr)
+    with open(os.path.join(OUT, "ref_online_cpp.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -307,6 +361,8 @@ if __name__ == "__main__":
         gen_uct_mixture()
     if "vanilla" in which:
         gen_vanilla()
+    if "online" in which:
+        gen_online()
     if "agents" in which:
         if params is None:
             params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]

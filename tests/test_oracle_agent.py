@@ -64,7 +64,7 @@ def test_agent_oracle_replays_reference_cpp_agent(oracle, golden_dir, idx):
     with open(os.path.join(golden_dir, "ref_cppagent.json")) as f:
         r = json.load(f)[idx]
     g = oracle.Game(seed=r["seed"])
-    a = oracle.Agent(2 if r["lp"] else 3, max_nodes=r["max_nodes"])
+    a = oracle.Agent(2 if r["lp"] else 3, max_nodes=r["max_nodes"], cpp_occupied=True)
     a.update_root(g)
     for i, (act, score, lines) in enumerate(r["moves"]):
         got = a.play(r["sims"])
