@@ -318,3 +318,68 @@ def test_pool_exhaustion_resets_the_tree_instead_of_undefined_behaviour():
         for m in range(40):
             strict.play()
             strict.store.sim_step(0)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_online_cpp_agent_training_sets(oracle, golden_dir, idx):
+    """ValueSimC(online=True) under the four accumulation policies of OnlineMCTSAgent (agent.cpp:619-816): every
+    training set handed to train() - device GC harvest -> ReplayMemory (drop / trim / policy) -> rendered states - is
+    identical to the oracle agent + oracle memory on the same run, and the 900 actions are the ones the reference's
+    compiled OnlineMCTSAgent played (tests/golden/ref_online_cpp.json).  The oracle runs WITHOUT the reference's
+    `occupied`-vector slip here: the product implements the intended GC, so its training sets
+    differ from the golden ones by the few tuples that slip withholds - pinned separately in tests/test_oracle_replay.py."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import replay_oracle as ro
+    with open(os.path.join(golden_dir, "ref_online_cpp.json")) as f:
+        r = json.load(f)[idx]
+    got_calls, want_calls, move = [], [], [0]
+
+    def payload(st, val, var, vis):
+        return dict(move=move[0], size=len(val), states_sha1=hashlib.sha1(st.astype(np.int8).tobytes()).hexdigest(),
+                    value=val.astype("<f4").tobytes().hex(), variance=var.astype("<f4").tobytes().hex(),
+                    visit=vis.astype("<f4").tobytes().hex())
+
+    def train(state, value, variance, visit, size):
+        assert state.shape == (size, 1, 20, 10)
+        got_calls.append(payload(state.cpu().numpy().reshape(size, 200), value.cpu().numpy().ravel(),
+                                 variance.cpu().numpy().ravel(), visit.cpu().numpy().ravel()))
+    game, agent = _make("ValueSimC", 1, r["sims"], r["max_nodes"], r["seed"], evaluator=hash_eval_torch, online=True,
+                        accumulation_policy=r["policy"], memory_size=r["memory_size"],
+                        episodes_per_train=r["episodes_per_train"], memory_growth_rate=r["growth"],
+                        min_visit=r["min_visit"], train=train, replay_cap=r["max_nodes"])
+    og = oracle.Game(seed=r["seed"])
+    oa = oracle.Agent(2, max_nodes=r["max_nodes"], online=True, min_visits_to_store=r["min_visit"], memory_size=1 << 20)
+    oa.update_root(og)
+    mem = ro.OnlineMemory(r["policy"], r["memory_size"], r["episodes_per_train"], r["growth"])
+    seen, n_gc = 0, 0
+    for m, act in enumerate(r["actions"]):
+        move[0] = m
+        got = agent.play()
+        assert got == act == oa.play(r["sims"]), m
+        if oa.n_gc != n_gc:
+            n_gc = oa.n_gc
+            st, val, var, vis = oa.memory()
+            batch = [(st[i], val[i], var[i], vis[i]) for i in range(seen, len(val))]
+            seen = len(val)
+            out = mem.remove_nodes(batch, oa.episode)
+            if out is not None:
+                want_calls.append(payload(np.stack([e[0] for e in out]), np.asarray([e[1] for e in out]),
+                                          np.asarray([e[2] for e in out]), np.asarray([e[3] for e in out])))
+        assert agent.memory.memory_index == mem.memory_index, m
+        game.play(got)
+        agent.update_root(game)
+        og.play(got)
+        oa.update_root(og)
+        if game.end:
+            game.reset()
+            agent.update_root(game)
+            og.reset()
+            oa.update_root(og)
+    assert agent.store.counter("N_GC") == oa.n_gc >= 7
+    assert len(want_calls) >= 4 and got_calls == want_calls
+    if r["policy"] in (0, 1):
+        # episode-driven policies train at the same moves as the reference's own run (the slip only changes how many
+        # tuples a GC yields, which moves the memory-driven policies 2 and 3)
+        assert [c["move"] for c in got_calls] == [c["move"] for c in r["train_calls"]]

@@ -18,6 +18,19 @@ def shard_range(n_total, rank, world):
     return start, base + (1 if rank < rem else 0)
 
 
+def rank(group=None):
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def all_sum(value, device="cpu", group=None):
+    """Sum of a Python integer over ranks (episode counters, harvest counts)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, group=group)
+    return int(t.item())
+
+
 def all_gather_tuples(obs_keys, stats, group=None):
     """All-gather variable-length training tuples.
 

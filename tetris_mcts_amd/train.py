@@ -93,7 +93,7 @@ def validation_loss(net, data, weighted, chunk=1024):
 
 
 def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validation_fraction=0.1,
-               sample_replacement=True, weighted=True, early_stopping=True, early_stopping_patience=10,
+               sample_replacement=True, oversampling=False, weighted=True, early_stopping=True, early_stopping_patience=10,
                early_stopping_threshold=1.0, shuffle=False, max_iters=100000, grad_clip=0.0, save=None, load=None,
                generator=None, log=True):
     """data = [states f32 [n,1,20,10], values [n,1], variances [n,1], weights [n,1]] (device tensors).
@@ -114,7 +114,9 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
     iters_done = 0
     net.train()
     for it in range(max_iters):
-        if sample_replacement:
+        if oversampling:    # model.py:194-195: draw proportionally to the visit weights
+            idx = torch.multinomial(train[3].reshape(-1), batch_size, replacement=sample_replacement, generator=generator)
+        elif sample_replacement:
             idx = torch.randint(0, n - n_val, (batch_size,), device=data[0].device, generator=generator)
         else:
             idx = torch.randperm(n - n_val, device=data[0].device, generator=generator)[:batch_size]
