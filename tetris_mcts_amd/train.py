@@ -110,7 +110,8 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
     if log:
         print("Training data size: {}    Validation data size: {}".format(n - n_val, n_val), file=stderr, flush=True)
     fails, best = 0, float("inf")
-    loss_avg = 0.0
+    loss_avg = torch.zeros((), device=data[0].device)      # running sums stay on the device: no sync per iteration
+    g_norm_avg = torch.zeros((), device=data[0].device)
     iters_done = 0
     net.train()
     for it in range(max_iters):
@@ -123,10 +124,12 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
         optimizer.zero_grad(set_to_none=True)
         loss, _ = batch_loss(net, [d[idx] for d in train], weighted)
         loss.backward()
+        # 2-norm over all parameter gradients (model.py:87-95), reported in the log line the dashboards parse
+        g_norm_avg += torch.sqrt(sum((p.grad.detach() ** 2).sum() for p in net.parameters() if p.grad is not None))
         if grad_clip > 0:
             torch.nn.utils.clip_grad_norm_(net.parameters(), grad_clip)
         optimizer.step()
-        loss_avg += float(loss.detach())
+        loss_avg += loss.detach()
         iters_done = it + 1
         if (it + 1) % iters_per_val == 0 and val is not None:
             net.eval()
@@ -145,9 +148,11 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
                 else:
                     fails += 1
             if log:
-                print("Iteration:{:7d}  training loss:{:6.4f}  validation loss:{:6.4f}±{:6.4f}    {}".format(
-                    it + 1, loss_avg / iters_per_val, vmean, vstd, mark), file=stderr, flush=True)
-            loss_avg = 0.0
+                print("Iteration:{:7d}  training loss:{:6.4f}  validation loss:{:6.4f}±{:6.4f}  gradient norm:{:6.3f}    {}"
+                      .format(it + 1, float(loss_avg) / iters_per_val, vmean, vstd, float(g_norm_avg) / iters_per_val, mark),
+                      file=stderr, flush=True)
+            loss_avg.zero_()
+            g_norm_avg.zero_()
             if early_stopping and fails >= early_stopping_patience:
                 break
     if early_stopping and load and best < float("inf"):
