@@ -234,8 +234,13 @@ def test_online_training_loop(tmp_path, monkeypatch):
     assert agent.store.counter("N_GC") >= 1
     n_tuples = int(agent.store.t["replay_count"].sum().item())
     assert n_tuples > 50
-    res = agent.train_nodes(iters_per_val=20, batch_size=256, max_iters=60)
+    res = agent.train_nodes(iters_per_val=20, batch_size=256, max_iters=60, dump_data=True,
+                            dump_path=str(tmp_path / "data" / "dump"))
     assert res is not None and res["iters"] >= 20
+    dump = np.load(str(tmp_path / "data" / "dump.npz"))       # the reference's replay dump layout (ValueSim.py:176-177)
+    assert sorted(dump.files) == ["states", "values", "variance", "weights"]
+    assert dump["states"].shape == (n_tuples, 1, 20, 10) and dump["weights"].shape == (n_tuples, 1)
+    assert set(np.unique(dump["states"])) <= {-1.0, 0.0, 1.0} and (dump["weights"] >= 3).all()
     after = model.flat_params()
     assert not torch.equal(before, after)
     assert int(agent.store.t["replay_count"].sum().item()) == 0

@@ -48,7 +48,20 @@ class ValueSim(TreeAgent):
     # ---- online training (ValueSim.py:161-185): the reference trains inside remove_nodes(), in the middle of a
     # simulation of its single game; the batched engine harvests tuples at GC time on the device and trains between
     # moves, on the union over all games and all ranks (tetris_mcts_amd/dist.py) ----
-    def train_nodes(self, dump_data=False, **train_kwargs):
+    @staticmethod
+    def dump_training_set(path, state, value, variance, visit):
+        """np.savez layout of the reference's replay dump (ValueSim.py:176-177, ValueSimC.py:8): keys states [n,1,20,10],
+        values / variance / weights [n,1]; written by rank 0 only."""
+        import os
+        import numpy as np
+        from .. import dist as tdist
+        if tdist.rank() != 0:
+            return
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        np.savez(path, states=state.cpu().numpy(), values=value.cpu().numpy(), variance=variance.cpu().numpy(),
+                 weights=visit.cpu().numpy())
+
+    def train_nodes(self, dump_data=False, dump_path="./data/dump", **train_kwargs):
         import torch
         from .. import dist as tdist
         from sys import stderr
@@ -70,6 +83,8 @@ class ValueSim(TreeAgent):
             return None
         print("Enough training data ({} >= {}), proceed to training.".format(d_size, m_size), file=stderr, flush=True)
         data = list(tdist.training_arrays(keys_all, stats_all))
+        if dump_data:
+            self.dump_training_set(dump_path, *data)
         self.n_trains += 1
         opts = dict(iters_per_val=100, batch_size=1024, max_iters=50000)
         opts.update(train_kwargs)

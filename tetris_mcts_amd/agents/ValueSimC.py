@@ -69,13 +69,8 @@ class ValueSimC(ValueSim):
 
     def training(self, state, value, variance, visit, d_size, **train_kwargs):
         """ValueSimC.py:6-14: dump the training set in the reference's np.savez layout, fit, back to inference mode."""
-        import os
-        import numpy as np
-        from .. import dist as tdist
-        if self.dump_path and tdist.rank() == 0:
-            os.makedirs(os.path.dirname(os.path.abspath(self.dump_path)), exist_ok=True)
-            np.savez(self.dump_path, states=state[:d_size].cpu().numpy(), values=value[:d_size].cpu().numpy(),
-                     variance=variance[:d_size].cpu().numpy(), weights=visit[:d_size].cpu().numpy())
+        if self.dump_path:
+            self.dump_training_set(self.dump_path, state[:d_size], value[:d_size], variance[:d_size], visit[:d_size])
         opts = dict(iters_per_val=100, batch_size=512, max_iters=50000, sample_replacement=True, oversampling=False)
         opts.update(train_kwargs)
         res = self.model.train_data([state[:d_size], value[:d_size], variance[:d_size], visit[:d_size]], **opts)
