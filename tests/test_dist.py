@@ -32,7 +32,13 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     k, s = _tuples(rank)
     ka, sa = tdist.all_gather_tuples(k, s)
-    q.put((rank, ka.numpy(), sa.numpy(), tdist.shard_range(4099, rank, world)))
+    # the online path of ValueSimC: episode counters are summed, every rank feeds the same union into its replay
+    # memory and therefore takes the same decision and trains on the same set
+    from tetris_mcts_amd.replay import ReplayMemory
+    episodes = tdist.all_sum(3 + rank)
+    mem = ReplayMemory(accumulation_policy=2, memory_size=6, episodes_per_train=50)
+    out = mem.absorb(ka, sa, episodes)
+    q.put((rank, ka.numpy(), sa.numpy(), tdist.shard_range(4099, rank, world), episodes, out[0].numpy(), tdist.rank()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,8 +58,10 @@ def test_all_gather_tuples_gloo_world2():
     exp_k = np.concatenate([_tuples(r)[0].numpy() for r in range(world)])
     exp_s = np.concatenate([_tuples(r)[1].numpy() for r in range(world)])
     shards = []
-    for rank, ka, sa, sh in sorted(res, key=lambda t: t[0]):
+    for rank, ka, sa, sh, episodes, train_keys, my_rank in sorted(res, key=lambda t: t[0]):
         assert np.array_equal(ka, exp_k) and sa.tobytes() == exp_s.tobytes()
+        assert episodes == 7 and my_rank == rank
+        assert np.array_equal(train_keys, exp_k[:6])       # policy 2: the memory (6 of the 7 tuples) filled up -> train
         shards.append(sh)
     assert shards[0][0] == 0 and shards[0][0] + shards[0][1] == shards[1][0] and shards[1][0] + shards[1][1] == 4099
 
