@@ -348,8 +348,50 @@ def gen_online():
         json.dump(out, f)
 
 
+def gen_online_py():
+    """The reference's Python ValueSim / ValueSimLP with online=True (ValueSim.py:101-159): the replay tuples
+    store_nodes() has put into agent.memory at every pool-exhaustion GC (train_nodes is replaced by a recorder that
+    empties the memory the way a training pass does, ValueSim.py:182)."""
+    import hashlib
+    out = []
+    for name, sims, seed in (("ValueSim", 40, 51), ("ValueSimLP", 30, 52)):
+        ref_shims.install()
+        from pyTetris import Tetris
+        ref_shims.srand(1)
+        agent = ref_shims.make_agent(name, sims, max_nodes=8000, evaluator=hash_eval, online=True, memory_size=50000)
+        agent.min_visits_to_store = 3       # ValueSimLP hard-codes 25 in its constructor (ValueSimLP.py:11)
+        calls, state = [], dict(move=0)
+
+        def record(dump_data=True, agent=agent, calls=calls, state=state):
+            n = agent.memory_index
+            st, val, var, w = [m[:n] for m in agent.memory]
+            calls.append(dict(move=state["move"], size=int(n),
+                              states_sha1=hashlib.sha1(np.ascontiguousarray(st).astype(np.int8).tobytes()).hexdigest(),
+                              value=np.ascontiguousarray(val, "<f4").tobytes().hex(),
+                              variance=np.ascontiguousarray(var, "<f4").tobytes().hex(),
+                              visit=np.ascontiguousarray(w, "<f4").tobytes().hex()))
+            agent.memory_index = 0
+        agent.train_nodes = record
+        game = Tetris((20, 10), 1, 0, 0, seed)
+        agent.update_root(game)
+        acts = []
+        for m in range(600):
+            state["move"] = m
+            a = int(agent.play())
+            game.play(a)
+            agent.update_root(game)
+            acts.append(a)
+            if game.end:
+                game.reset()
+                agent.update_root(game)
+        out.append(dict(name=name, sims=sims, seed=seed, max_nodes=8000, min_visits_to_store=3, actions=acts, harvests=calls))
+        print(name, "online: GCs", len(calls), "sizes", [c["size"] for c in calls], file=sys.stderr)
+    with open(os.path.join(OUT, "ref_online_py.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -363,6 +405,8 @@ if __name__ == "__main__":
         gen_vanilla()
     if "online" in which:
         gen_online()
+    if "online_py" in which:
+        gen_online_py()
     if "agents" in which:
         if params is None:
             params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]

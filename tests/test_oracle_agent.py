@@ -109,3 +109,33 @@ def test_mt19937_randint_matches_cpython(oracle):
         st = np.asarray(r.getstate()[1], dtype=np.uint64).astype(np.uint32)
         got = [oracle.lib().orc_mt_randint7_test(oracle.ptr(st)) for _ in range(2000)]
         assert got == [r.randint(0, 6) for _ in range(2000)]
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_store_nodes_matches_reference_python_agents(oracle, golden_dir, idx):
+    """tests/golden/ref_online_py.json: what the reference's ValueSim / ValueSimLP (online=True) put into agent.memory at
+    every GC (store_nodes, ValueSim.py:122-159) - states, values, variances, visit weights, in order."""
+    import hashlib
+    with open(os.path.join(golden_dir, "ref_online_py.json")) as f:
+        r = json.load(f)[idx]
+    g = oracle.Game(seed=r["seed"])
+    a = oracle.Agent({"ValueSim": 0, "ValueSimLP": 1}[r["name"]], max_nodes=r["max_nodes"], online=True,
+                     memory_size=1 << 18, min_visits_to_store=r["min_visits_to_store"])
+    a.update_root(g)
+    got, seen, n_gc = [], 0, 0
+    for m, act in enumerate(r["actions"]):
+        assert a.play(r["sims"]) == act, m
+        if a.n_gc != n_gc:
+            n_gc = a.n_gc
+            st, val, var, vis = a.memory()
+            got.append(dict(move=m, size=len(val) - seen, states_sha1=hashlib.sha1(st[seen:].tobytes()).hexdigest(),
+                            value=val[seen:].astype("<f4").tobytes().hex(), variance=var[seen:].astype("<f4").tobytes().hex(),
+                            visit=vis[seen:].astype("<f4").tobytes().hex()))
+            seen = len(val)
+        g.play(act)
+        a.update_root(g)
+        if g.end:
+            g.reset()
+            a.update_root(g)
+    assert len(got) >= 3 and got == r["harvests"]
+    a.close()
