@@ -111,7 +111,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int PREP_W2 = 0, PREP_W3 = 9216, PREP_W1 = 18432, PREP_TOTAL = 18432 + 458752;
 constexpr int A1CS = 145;   // conv1-output channel stride in LDS (18*8 = 144, +1 against bank conflicts)
 constexpr int A2CS = 97;    // conv2-output channel stride in LDS (16*6 = 96, +1)
+// TM_CONV_WG_PER_CU = 2: conv2's outputs live in registers until its last LDS read of a1 has been issued, so a2 can
+// take a1's place; a wave then needs 19.4 KB instead of 31.8 KB and two workgroups (8 waves) fit a CU's 160 KB: the
+// vector-ALU phases of one wave (render, conv1, epilogues) run under the other wave's MFMAs.
+#ifndef TM_CONV_WG_PER_CU
+#define TM_CONV_WG_PER_CU 2   // measured (r01): 118 us -> 104 us per launch of 4096 states
+#endif
+#ifndef TM_CONV_SKIP
+#define TM_CONV_SKIP 0   // timing experiments only: bit 0 conv1, bit 1 conv2's MFMAs, bit 2 conv3's MFMAs compiled out
+#endif
+#if TM_CONV_WG_PER_CU == 2
+constexpr int WAVE_LDS = 32 * A1CS + 200;               // floats per wave: a1 (a2 overlays it), input
+#else
 constexpr int WAVE_LDS = 32 * A1CS + 32 * A2CS + 200;   // floats per wave: a1, a2, input
+#endif
 
 __global__ void k_vn_prepare(const float* __restrict__ P, float* __restrict__ prep) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,6 +201,9 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, const in
 // Input: either int8 states [n][200], or (states == nullptr) evaluation requests of the tree engine:
 // request s refers to packed observation eval_obs[s] of game s / eval_slots (ENGINE_SPEC.md section 7), rendered
 // here on the fly (0 empty, 1 locked, -1 falling piece; request 0 = unused slot = empty board).
+#if TM_CONV_WG_PER_CU == 2 && !defined(TM_CONV_CAP256)
+#define TM_CONV_CAP256   // two waves per SIMD: 256 registers each
+#endif
 #ifdef TM_CONV_CAP256
 #define TM_CONV_WAVES 2
 #else
@@ -200,8 +216,13 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
     float* a1 = smem + w * WAVE_LDS;
+#if TM_CONV_WG_PER_CU == 2
+    float* a2 = a1;
+    float* x0 = a1 + 32 * A1CS;
+#else
     float* a2 = a1 + 32 * A1CS;
     float* x0 = a2 + 32 * A2CS;
+#endif
     // ---- per-lane constants ----
     int koff2[9], koff3[9];   // offsets of k = 2j+half inside a two-channel block
 #pragma unroll
@@ -269,6 +290,7 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
         }
         lds_fence();
         // ---- conv1 on the vector ALUs: lanes = output positions (18x8), weights as scalars ----
+#if !(TM_CONV_SKIP & 1)
         {
             float xin[3][9];
             int pp[3];
@@ -295,6 +317,7 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
                 }
             }
         }
+#endif
         lds_fence();
         // ---- conv2: 96 positions = 3 tiles ----
         {
@@ -303,7 +326,12 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = bias2[r];
+#if !(TM_CONV_SKIP & 2)
             conv_mfma<3, A1CS>(a1, boff2, W2s, acc);
+#endif
+#if TM_CONV_WG_PER_CU == 2
+            lds_fence();   // a2 overlays a1: every read of a1 is complete before the first write
+#endif
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -321,7 +349,9 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = bias3[r];
+#if !(TM_CONV_SKIP & 4)
             conv_mfma<2, A2CS>(a2, boff3, W3s, acc);
+#endif
             float* dst = a3out + (size_t)s * a3stride;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -495,7 +525,7 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
         attr_set = true;
     }
     int blocks = (n + 3) / 4;
-    if (blocks > 256) blocks = 256;   // one workgroup per CU, waves stride over the states
+    if (blocks > 256 * TM_CONV_WG_PER_CU) blocks = 256 * TM_CONV_WG_PER_CU;   // resident workgroups, waves stride over the states
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, eval_obs,
                        eval_slots, max_nodes, n, scratch, SS);
     hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(512), 0, stream, P, prepared, scratch, SS, n,
