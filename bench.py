@@ -111,6 +111,9 @@ def main():
     K = stores[0].eval_slots
 
     ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(sims)] for _ in range(NS)] if not args.graph else None
+    # HIP events bracket every EV_EVERY-th simulation of the timed region (two event records per launch cost ~7 us of
+    # stream time per simulation, 3 % of a step, when placed around all of them)
+    EV_EVERY = int(os.environ.get("TM_BENCH_EVENT_EVERY", "16"))
     t_tree = t_nn = 0.0
     n_tree = n_nn = 0
     episodes, lines = 0, 0
@@ -125,12 +128,12 @@ def main():
             for i in range(sims):
                 for k in range(NS):
                     with torch.cuda.stream(streams[k]):
-                        e = ev[k][i]
-                        e[0].record()
+                        e = ev[k][i] if i % EV_EVERY == 0 else None
+                        if e: e[0].record()
                         stores[k].sim_step(st.SIM_BACKUP | st.SIM_FRONT)
-                        e[1].record()
+                        if e: e[1].record()
                         agts[k].evaluate_requests()
-                        e[2].record()
+                        if e: e[2].record()
             for k in range(NS):
                 with torch.cuda.stream(streams[k]):
                     stores[k].sim_step(st.SIM_BACKUP)
@@ -148,11 +151,11 @@ def main():
         if timed and not args.graph:
             torch.cuda.synchronize()
             for k in range(NS):
-                for e in ev[k]:
+                for e in ev[k][::EV_EVERY]:
                     t_tree += e[0].elapsed_time(e[1])
                     t_nn += e[1].elapsed_time(e[2])
-            n_tree += sims * NS
-            n_nn += sims * NS
+            n_tree += len(ev[0][::EV_EVERY]) * NS
+            n_nn += len(ev[0][::EV_EVERY]) * NS
 
     def counters():
         return {k: sum(S.counter(k) for S in stores) for k in ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL")}
@@ -227,13 +230,14 @@ def main():
                    "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1", "tmcts_vn::k_fc_out"], 2.0)
                    if args.backend == "hip" else None,
                    "traffic_note": "bytes/launch, FETCH_SIZE x2 (wide streams) + WRITE_SIZE from profiles/r01_pmc_traffic.json",
-                   "avg_launch_ms": nn_ms}
+                   "avg_launch_ms": nn_ms, "launches_timed": int(n_nn), "events_every": EV_EVERY}
         tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % Gs, "bound": "hbm",
                      "achieved": a_gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBPS,
                      "traffic": pmc_traffic(["tmcts::k_sim_step<false>"]),
                      "traffic_note": "bytes/launch of 4096 games at mean trace length ~20 (move 1), FETCH_SIZE + WRITE_SIZE "
                                      "from profiles/r01_pmc_traffic.json (narrow scattered accesses: no gfx950 correction)",
-                     "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps}
+                     "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps, "launches_timed": int(n_tree),
+                     "events_every": EV_EVERY}
         out["roofline"] = nn_roof if nn_ms >= tree_ms else tree_roof
         out["roofline_other"] = tree_roof if nn_ms >= tree_ms else nn_roof
     if world == 1 and not args.no_cpu_baseline:

@@ -251,30 +251,46 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
         bias2[r] = P[OFF_C2B + i];
         bias3[r] = P[OFF_C3B + i];
     }
+    float w1[5];      // conv1 weights: A operand of step st = W1[co = l31][k = 2 st + half], k = 9 is the zero pad
+    int koff1[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int k = 2 * st + half;
+        w1[st] = (k < 9) ? P[OFF_C1W + l31 * 9 + k] : 0.0f;
+        koff1[st] = (k < 9) ? (k / 3) * 10 + (k % 3) : 0;
+    }
     const float4* W2 = reinterpret_cast<const float4*>(prep + PREP_W2) + lane;
     const float4* W3 = reinterpret_cast<const float4*>(prep + PREP_W3) + lane;
 
-    for (int s = blockIdx.x * 4 + w; s < n; s += gridDim.x * 4) {
-#ifdef TM_CONV_CAP256
-        // variant: weight streams re-read per state (an opaque zero offset defeats hoisting) so the kernel fits in
-        // 256 registers and other wavefronts can share its SIMDs
+    // Evaluation requests: the two dependent global reads per state (request -> packed observation) are issued one
+    // state ahead, so they are in flight under the previous state's convolutions instead of in front of this one's.
+    const int stride = gridDim.x * 4;
+    int s = blockIdx.x * 4 + w;
+    int o_next = (!states && s < n) ? eval_obs[s] : 0;
+    uint32_t kw_next = 0;
+    if (!states && s < n && lane < 12) kw_next = obs_key[((size_t)(s / eval_slots) * max_nodes + o_next) * 12 + lane];
+    for (; s < n; s += stride) {
+        // weight streams re-read per state (an opaque zero offset defeats hoisting them into ~290 registers) so the
+        // kernel fits in 256 registers and two waves share a SIMD
         int zoff = 0;
         asm volatile("" : "+s"(zoff));
         const float4* W2s = W2 + zoff;
         const float4* W3s = W3 + zoff;
-#else
-        const float4* W2s = W2;
-        const float4* W3s = W3;
-#endif
-        // unused evaluation slots (request 0) are skipped: their outputs are never read
-        if (!states && eval_obs[s] == 0) continue;
+        const int o = o_next;
+        const uint32_t kw = kw_next;
+        const int sn = s + stride;
+        if (!states) {
+            o_next = (sn < n) ? eval_obs[sn] : 0;
+            // unused evaluation slots (request 0) are skipped: their outputs are never read
+            if (o == 0) {
+                kw_next = (sn < n && lane < 12) ? obs_key[((size_t)(sn / eval_slots) * max_nodes + o_next) * 12 + lane] : 0u;
+                continue;
+            }
+        }
         // ---- input ----
         if (states) {
             for (int i = lane; i < 200; i += 64) x0[i] = (float)states[(size_t)s * 200 + i];
         } else {
-            const int o = eval_obs[s];
-            const uint32_t* key = obs_key + ((size_t)(s / eval_slots) * max_nodes + o) * 12;
-            uint32_t kw = (lane < 12) ? key[lane] : 0u;
             const uint32_t cells = __shfl((int)kw, 10, 64), endw = __shfl((int)kw, 11, 64);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {   // uniform trip count: the shuffles below need every lane active
@@ -285,35 +301,31 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
                 bool pc = ((cells & 0xFF) == (uint32_t)ic) | (((cells >> 8) & 0xFF) == (uint32_t)ic) |
                           (((cells >> 16) & 0xFF) == (uint32_t)ic) | ((cells >> 24) == (uint32_t)ic);
                 if (!(endw & 0xFFu) && pc) v = -1.0f;
-                if (i < 200) x0[i] = (o == 0) ? 0.0f : v;
+                if (i < 200) x0[i] = v;
             }
+            // the next state's observation: its request index has had the whole input stage to arrive
+            kw_next = (sn < n && lane < 12) ? obs_key[((size_t)(sn / eval_slots) * max_nodes + o_next) * 12 + lane] : 0u;
         }
         lds_fence();
-        // ---- conv1 on the vector ALUs: lanes = output positions (18x8), weights as scalars ----
+        // ---- conv1 (K = 9) on the matrix cores as well: 144 positions = 5 tiles (the last one half padding), 5 steps of
+        // two taps; the tenth tap has weight 0, and fma(0, b, acc) returns acc unchanged for the finite b read there ----
 #if !(TM_CONV_SKIP & 1)
         {
-            float xin[3][9];
-            int pp[3];
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj) {
-                int p = lane + 64 * jj;
-                pp[jj] = p;
-                int pc = min(p, 143), y = pc >> 3, x = pc & 7;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) xin[jj][ky * 3 + kx] = x0[(y + ky) * 10 + x + kx];
-            }
 #pragma unroll 1
-            for (int co = 0; co < 32; ++co) {
-                const float* wc = P + OFF_C1W + co * 9;
-                const float b = P[OFF_C1B + co];
+            for (int t = 0; t < 5; ++t) {
+                const int p = 32 * t + l31, pc = min(p, 143), base = (pc >> 3) * 10 + (pc & 7);
+                f32x16 acc;
 #pragma unroll
-                for (int jj = 0; jj < 3; ++jj) {
-                    float acc = b;
+                for (int r = 0; r < 16; ++r) acc[r] = P[OFF_C1B + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) acc = fmaf(xin[jj][k], wc[k], acc);
-                    if (pp[jj] < 144) a1[co * A1CS + pp[jj]] = acc > 0.0f ? acc : 0.0f;
+                for (int st = 0; st < 5; ++st)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], x0[base + koff1[st]], acc, 0, 0, 0);
+                if (p < 144) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        a1[i * A1CS + p] = acc[r] > 0.0f ? acc[r] : 0.0f;
+                    }
                 }
             }
         }
