@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from gpu_helpers import hash_eval_torch
 from tetris_mcts_amd import agents, store as st
 from tetris_mcts_amd.pyTetris import Tetris
-for mn, sims in ((20000, 100), (100000, 200)):
+CASES = {"small": ((20000, 100),), "large": ((100000, 200),), "all": ((20000, 100), (100000, 200))}
+for mn, sims in CASES[sys.argv[1] if len(sys.argv) > 1 else "all"]:
     G = 256
     game = Tetris((20, 10), 1, 0, 0, seed=7, n_games=G)
     agent = agents.ValueSimLP(sims=sims, env=Tetris, env_args=game.env_args, n_games=G, max_nodes=mn, evaluator=hash_eval_torch)

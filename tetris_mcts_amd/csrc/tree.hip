@@ -282,7 +282,9 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         dst[0] = make_uint4(ok[0], ok[1], ok[2], ok[3]);
         dst[1] = make_uint4(ok[4], ok[5], ok[6], ok[7]);
         dst[2] = make_uint4(ok[8], ok[9], ok[10], ok[11]);
-        P.stat[(size_t)o * 4 + 3] = ok[11] & 0xFFu;  // obs_arrays['end'] (agents/agent.py:123)
+        // visit, value, variance = 0 and obs_arrays['end'] (agents/agent.py:123): slots are initialised when they are
+        // handed out, so the GC does not have to clear the key / record streams of everything it frees
+        *reinterpret_cast<uint4*>(P.stat + (size_t)o * 4) = make_uint4(0u, 0u, 0u, ok[11] & 0xFFu);
     }
     {   // same observation as an earlier new candidate
         int osrc = shfl_u32((uint32_t)o, odup);
@@ -294,10 +296,16 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         dst[1] = make_uint4(my[4], my[5], my[6], my[7]);
         dst[2] = make_uint4(my[8], my[9], my[10], my[11]);
         dst[3] = make_uint4(my[12], my[13], my[14], my[15]);
-        uint32_t* r = P.rec + (size_t)idx * TM_REC_DW;
-        r[TM_REC_HDR] = ((my[11] >> 8) & 1u) << 24;          // end flag of the node's game
-        r[TM_REC_OBS] = (uint32_t)o;                         // node_to_obs
-        r[TM_REC_SCORE] = __float_as_uint((float)(int)my[14]);   // arrays['score'][idx] = game.score (float32)
+        // the whole record: no children yet (slot triples and raw child row zero), then hdr = end flag of the node's
+        // game, node_to_obs, arrays['score'][idx] = game.score (float32)
+        static_assert(TM_REC_HDR == 21 && TM_REC_OBS == 22 && TM_REC_SCORE == 23 && TM_REC_DW == 24 && TM_KIDS_DW == 8,
+                      "record layout");
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        uint4* r = reinterpret_cast<uint4*>(P.rec + (size_t)idx * TM_REC_DW);
+        r[0] = z; r[1] = z; r[2] = z; r[3] = z; r[4] = z;
+        r[5] = make_uint4(0u, ((my[11] >> 8) & 1u) << 24, (uint32_t)o, __float_as_uint((float)(int)my[14]));
+        uint4* kd = reinterpret_cast<uint4*>(P.kids + (size_t)idx * TM_KIDS_DW);
+        kd[0] = z; kd[1] = z;
     }
     if (uniq && found) o = (int)P.rec[(size_t)found * TM_REC_DW + TM_REC_OBS];
     {
@@ -804,13 +812,13 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
     uint8_t* omark = nmark + bm_bytes;
     int32_t* queue = S.gc_queue + (size_t)g * N;
     const uint32_t mask = (uint32_t)S.table_cap - 1u;
-    __threadfence();
+    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
     for (size_t i = lane; i < 2 * bm_bytes / 4; i += 64) reinterpret_cast<uint32_t*>(nmark)[i] = 0;
-    __threadfence();
+    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
     // breadth-first marking; index 0 is followed like any other child (core.h:41-45), so it stays occupied
     int head = 0, tail = 1;
     if (lane == 0) { queue[0] = P.gs[TM_GS_ROOT]; bit_test_set(nmark, (uint32_t)queue[0]); }
-    __threadfence();
+    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
     while (head < tail) {
         int i = head + lane;
         int cnt = 0;
@@ -848,10 +856,15 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
         __threadfence_block();
     }
     // the root of an unexpanded tree still reaches node 0 through its zero child row
-    __threadfence();
+    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
     // both tables are rebuilt from what is kept: clear them first (nothing below reads them)
-    for (size_t i = lane; i < (size_t)S.table_cap; i += 64) { P.ntab[i] = 0; P.otab[i] = 0; }
-    __threadfence();
+    {   // 16-byte stores: two 8-byte entries each (table_cap is a power of two, the per-game tables are 16-byte aligned)
+        uint4* nt4 = reinterpret_cast<uint4*>(P.ntab);
+        uint4* ot4 = reinterpret_cast<uint4*>(P.otab);
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        for (size_t i = lane; i < (size_t)S.table_cap / 2; i += 64) { nt4[i] = z4; ot4[i] = z4; }
+    }
+    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
     // Sweeps over the pool: each lane takes one 32-bit word of a bitmap = 32 consecutive indices per pass (2048 per
     // wave pass), so a 100 000-entry pool is 49 passes instead of 1563 dependent ones.  Free lists come out ascending
     // (agents/agent.py:211-212,221-222): lane-major order is index order, positions from a wave prefix sum.  Freed
@@ -881,31 +894,9 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
         const uint32_t fr = (wi < n_words) ? (~nw[wi] & valid) : 0u;
         int total;
         int pos = nfree + wave_scan(__popc(fr), total) - __popc(fr);
-        // words that are entirely free (the common case: freed indices come in long runs) are cleared by the whole
-        // wave with contiguous 16-byte stores; only partially free words fall back to per-lane scattered stores.
-        // (A freed node's node_to_obs is cleared too: the reference leaves it stale, agents/agent.py:234-235, but
-        // nothing ever reads it before new_node overwrites it.)
-        const bool nfull = (wi < n_words) && valid == 0xFFFFFFFFu && fr == 0xFFFFFFFFu && (wi * 32 >= low_node);
-        for (uint64_t fm = __ballot(nfull); fm; fm &= fm - 1) {
-            const int w0 = (wbase + (__ffsll((long long)fm) - 1)) * 32;     // first node of a fully free word
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            uint4* r = reinterpret_cast<uint4*>(P.rec + (size_t)w0 * TM_REC_DW);       // 32 x 96 B = 192 uint4
-            r[lane] = z; r[64 + lane] = z; r[128 + lane] = z;
-            reinterpret_cast<uint4*>(P.kids + (size_t)w0 * TM_KIDS_DW)[lane] = z;      // 32 x 32 B = 64 uint4
-        }
-        for (uint32_t bits = fr; bits; bits &= bits - 1) {
-            const int i = wi * 32 + (__ffs(bits) - 1);
-            P.fnode[pos++] = i;
-            if (i >= low_node && !nfull) {
-                uint4* r = reinterpret_cast<uint4*>(P.rec + (size_t)i * TM_REC_DW);
-                const uint4 z = make_uint4(0, 0, 0, 0);
-                r[0] = z; r[1] = z; r[2] = z; r[3] = z; r[4] = z;
-                uint32_t* rr = P.rec + (size_t)i * TM_REC_DW;
-                rr[20] = 0; rr[TM_REC_HDR] = 0; rr[TM_REC_SCORE] = 0;     // TM_REC_OBS (node_to_obs) is not reset by the reference
-                uint4* kd = reinterpret_cast<uint4*>(P.kids + (size_t)i * TM_KIDS_DW);
-                kd[0] = z; kd[1] = z;
-            }
-        }
+        // Freed records are not cleared here: new_node initialises a slot completely when it hands it out (the
+        // reference zeroes at GC, agents/agent.py:227-244; nothing reads a free slot in between).
+        for (uint32_t bits = fr; bits; bits &= bits - 1) P.fnode[pos++] = wi * 32 + (__ffs(bits) - 1);
         nfree += total;
         // ---- observations ----
         const uint32_t ofr = (wi < n_words) ? (~ow[wi] & valid) : 0u;
@@ -958,29 +949,22 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
             const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)o;
             while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.otab[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
         }
+        // Of a freed observation only the statistics are cleared (16 B): a visit count of 0 is what keeps a slot that
+        // stays free from being harvested again at the next GC.  Fully free words: one contiguous 512-byte store.
         const bool ofull = (wi < n_words) && valid == 0xFFFFFFFFu && ofr == 0xFFFFFFFFu && (wi * 32 >= low_obs);
         for (uint64_t fm = __ballot(ofull); fm; fm &= fm - 1) {
             const int w0 = (wbase + (__ffsll((long long)fm) - 1)) * 32;
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            if (lane < 32) reinterpret_cast<uint4*>(P.stat + (size_t)w0 * 4)[lane] = z;            // 32 x 16 B
-            uint4* k4 = reinterpret_cast<uint4*>(P.okey + (size_t)w0 * TM_OBS_DW);                 // 32 x 48 B = 96 uint4
-            k4[lane] = z;
-            if (lane < 32) k4[64 + lane] = z;
+            if (lane < 32) reinterpret_cast<uint4*>(P.stat + (size_t)w0 * 4)[lane] = make_uint4(0, 0, 0, 0);
         }
         for (uint32_t bits = ofr; bits; bits &= bits - 1) {
             const int o = wi * 32 + (__ffs(bits) - 1);
             P.fobs[opos++] = o;
-            if (o >= low_obs && !ofull) {
-                const uint4 z = make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(P.stat + (size_t)o * 4) = z;
-                uint4* k4 = reinterpret_cast<uint4*>(P.okey + (size_t)o * TM_OBS_DW);
-                k4[0] = z; k4[1] = z; k4[2] = z;
-            }
+            if (o >= low_obs && !ofull) *reinterpret_cast<uint4*>(P.stat + (size_t)o * 4) = make_uint4(0, 0, 0, 0);
         }
         onfree += ototal;
     }
     if (harvest && lane == 0) S.replay_count[g] = m;
-    __threadfence();
+    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
     // re-insert the kept nodes (the BFS queue lists them)
     // parallel reinsertion: lanes claim empty slots with a 64-bit compare-and-swap (no deletions happen
     // concurrently, so linear probing stays consistent; placement order does not affect lookups)
@@ -1004,7 +988,7 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
         P.gs[TM_GS_CYC_TAIL] = (int)((__builtin_readcyclecounter() - gc_t0) >> 4);   // last GC, in units of 16 cycles
         P.gs[TM_GS_CYC_TAIL + 1] = tail;                                                // reachable nodes at the last GC
     }
-    __threadfence();
+    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
     (void)L;
 }
 
