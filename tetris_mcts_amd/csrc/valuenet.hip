@@ -388,7 +388,10 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
 // tiles (two independent accumulators), two waves per SIMD so one wave's LDS / L2 waits hide behind the other's
 // MFMAs.  Activations are staged through LDS in 128-wide K chunks, weight quads double-buffered in registers.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int FC_KC = 128, FC_PITCH = 132;
+#ifndef TM_FC_KC
+#define TM_FC_KC 256   // 7 chunks (half the workgroup barriers of 128): fc1 39.2 -> 36.5 us
+#endif
+constexpr int FC_KC = TM_FC_KC, FC_PITCH = FC_KC + 4;
 __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
                                                 float* __restrict__ hout, int hstride) {
@@ -400,23 +403,24 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     f32x4 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc0[r] = acc1[r] = P[OFF_F1B + 16 * ht + kk * 4 + r];
-    // staging: 32 rows x 128 floats per chunk = 1024 float4, two per thread (rows row0, row0 + 16)
-    const int row0 = threadIdx.x >> 5, c4 = (threadIdx.x & 31) * 4;
-    float4 st[2];
+    // staging: 32 rows x FC_KC floats per chunk, FC_KC/4 threads per row, 16-byte pieces
+    constexpr int TPR = FC_KC / 4, RPP = 512 / TPR, NPASS = 32 / RPP;
+    const int row0 = threadIdx.x / TPR, c4 = (threadIdx.x % TPR) * 4;
+    float4 st[NPASS];
     auto gload = [&](int chunk) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int sa = s0 + row0 + 16 * i;
+        for (int i = 0; i < NPASS; ++i) {
+            int sa = s0 + row0 + RPP * i;
             st[i] = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4)
                              : make_float4(0, 0, 0, 0);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<float4*>(&bt[buf][(row0 + 16 * i) * FC_PITCH + c4]) = st[i];
+        for (int i = 0; i < NPASS; ++i)
+            *reinterpret_cast<float4*>(&bt[buf][(row0 + RPP * i) * FC_PITCH + c4]) = st[i];
     };
-    constexpr int NCH = A3 / FC_KC;   // 14 chunks of 128 k = 32 MFMA steps = 8 weight quads
+    constexpr int NCH = A3 / FC_KC;   // chunks of FC_KC k = FC_KC/4 MFMA steps = FC_KC/16 weight quads
     constexpr int QPC = FC_KC / 16;
     float4 wbuf[2][QPC];
     auto wload = [&](int chunk, int buf) {
