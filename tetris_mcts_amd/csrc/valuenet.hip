@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __r
 // B[k=l>>4][j=l&15], D[i=(l>>4)*4+r][j=l&15]; per output a k-ordered fma chain, 4 terms per instruction).
 // A workgroup of 8 waves owns 32 states x 128 hidden units: every wave a 16-row hidden tile and both 16-state
 // tiles (two independent accumulators), two waves per SIMD so one wave's LDS / L2 waits hide behind the other's
-// MFMAs.  Activations are staged through LDS in 128-wide K chunks, weight quads double-buffered in registers.
+// MFMAs.  Activations are staged through LDS in FC_KC-wide K chunks, weight quads double-buffered in registers.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef TM_FC_KC
 #define TM_FC_KC 256   // 7 chunks (half the workgroup barriers of 128): fc1 39.2 -> 36.5 us
