@@ -20,22 +20,22 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
 template <int CHAINS>
 void run(int wgs, const char* tag) {
     float* out;
-    hipMalloc(&out, (size_t)wgs * 256 * 4);
+    (void)hipMalloc(&out, (size_t)wgs * 256 * 4);
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int iters = 20000;
     k<CHAINS><<<wgs, 256>>>(out, 1000, 1.0f, 0.5f);
-    hipDeviceSynchronize();
-    hipEventRecord(e0);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
     k<CHAINS><<<wgs, 256>>>(out, iters, 1.0f, 0.5f);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
     float ms;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     double flops = (double)wgs * 4 * iters * CHAINS * 4096.0;
     printf("%s: %d WGs x 4 waves, %d chains: %.3f ms, %.1f TFLOP/s, implied clock at 64 cyc/MFMA %.3f GHz\n", tag, wgs, CHAINS, ms,
            flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 2.4);
-    hipFree(out);
+    (void)hipFree(out);
 }
 int main() {
     run<4>(256, "1 wave/SIMD");
