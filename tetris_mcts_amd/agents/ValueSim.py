@@ -15,7 +15,9 @@ class ValueSim(TreeAgent):
                  max_nodes=100000, model=None, evaluator=None, **kwargs):
         kwargs.pop("min_visit", None)  # play.py:89 forwards it; the reference ValueSim ignores it too
         benchmark = kwargs.get("benchmark", False)
-        kwargs.setdefault("replay_cap", 4096 if (online and not benchmark) else 0)
+        # device-side harvest buffer per game (64 B per tuple); a GC at a 100 000-entry pool frees a few thousand
+        # observations with enough visits, and whatever exceeds the buffer between two drains is dropped
+        kwargs.setdefault("replay_cap", min(int(max_nodes), 16384) if (online and not benchmark) else 0)
         super().__init__(max_nodes=max_nodes, gamma=gamma, online=(online and not benchmark),
                          min_visits_to_store=min_visits_to_store, **kwargs)
         self.online = online
