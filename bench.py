@@ -52,8 +52,8 @@ def main():
     global np
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)     # 5 warm-up moves, then 20 timed moves
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--games", type=int, default=4096, help="games per GPU")
     ap.add_argument("--sims", type=int, default=500)
     ap.add_argument("--agent", default="ValueSim", choices=["ValueSim", "ValueSimLP"])
