@@ -6,7 +6,6 @@ pools and RNG streams.  The only exchange is the all-gather of the (state, TD-ta
 harvests (ValueSim.store_nodes, ValueSim.py:122-159), so every rank can train the same replica on the union.
 Backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -10,7 +10,6 @@ the GPU (plumbing, not a hot kernel):
   * checkpoint format                   model/model.py:143-174 ({'model_state_dict', 'optimizer_state_dict'})
 """
 import math
-import os
 from sys import stderr
 
 import torch
