@@ -1,0 +1,55 @@
+"""The two summarisers that turn rocprofv3 csv output into what profiles/ holds (scripts/kernel_stats.py,
+scripts/pmc_traffic.py) and bench.py's reader of the committed PMC file, on tiny synthetic traces."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write(path, header, rows):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(header)
+        w.writerows(rows)
+
+
+def test_kernel_stats_summary(tmp_path):
+    hdr = ["Kind", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
+           "LDS_Block_Size", "Scratch_Size"]
+    rows = [["KERNEL_DISPATCH", "void tmcts::k_sim_step<false>(tm_store, int)", 100, 190, 64, 0, 112, 16896, 32],
+            ["KERNEL_DISPATCH", "void tmcts::k_sim_step<false>(tm_store, int)", 300, 410, 64, 0, 112, 16896, 32],
+            ["KERNEL_DISPATCH", "tmcts_vn::k_vn_fc1(float const*)", 500, 540, 52, 0, 32, 33792, 0]]
+    _write(str(tmp_path / "run" / "1_kernel_trace.csv"), hdr, rows)
+    out = tmp_path / "stats.csv"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "kernel_stats.py"), str(tmp_path / "run"), str(out)])
+    got = list(csv.DictReader(open(out)))
+    assert [g["Name"] for g in got] == ["void tmcts::k_sim_step<false>(tm_store, int)", "tmcts_vn::k_vn_fc1(float const*)"]
+    assert got[0]["Calls"] == "2" and float(got[0]["AverageNs"]) == 100.0 and got[0]["MinNs"] == "90" and got[0]["MaxNs"] == "110"
+    assert abs(float(got[0]["Percentage"]) - 100.0 * 200 / 240) < 1e-2 and got[1]["LDS"] == "33792"
+
+
+def test_pmc_traffic_summary_and_bench_reader(tmp_path, monkeypatch):
+    hdr = ["Kernel_Name", "Counter_Name", "Counter_Value"]
+    for counter, vals in (("FETCH_SIZE", (10.0, 30.0)), ("WRITE_SIZE", (4.0, 8.0))):
+        rows = [["void tmcts::k_sim_step<false>(tm_store, int)", counter, v] for v in vals]
+        rows.append(["__amd_rocclr_copyBuffer", counter, 1.0])           # foreign kernels are left out
+        _write(str(tmp_path / counter / "p_counter_collection.csv"), hdr, rows)
+    oj, oc = tmp_path / "t.json", tmp_path / "t.csv"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic.py"), str(oj), str(oc),
+                           str(tmp_path / "FETCH_SIZE"), str(tmp_path / "WRITE_SIZE")])
+    k = json.load(open(oj))["kernels"]
+    assert list(k) == ["tmcts::k_sim_step<false>"]
+    assert k["tmcts::k_sim_step<false>"]["FETCH_SIZE_KB_mean"] == 20.0 and k["tmcts::k_sim_step<false>"]["launches"] == 2
+    # bench.py reads the same structure: bytes = 1024 * (fetch_scale * FETCH + WRITE) of the last-50 means
+    sys.path.insert(0, ROOT)
+    import bench
+    os.makedirs(tmp_path / "profiles")
+    os.replace(oj, tmp_path / "profiles" / "r01_pmc_traffic.json")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic(["tmcts::k_sim_step<false>"]) == 1024.0 * (20.0 + 6.0)
+    assert bench.pmc_traffic(["tmcts::k_sim_step<false>"], 2.0) == 1024.0 * (40.0 + 6.0)
+    assert bench.pmc_traffic(["tmcts_vn::k_vn_conv"]) is None
