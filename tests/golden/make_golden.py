@@ -390,8 +390,50 @@ def gen_online_py():
         json.dump(out, f)
 
 
+def gen_agents_env():
+    """Reference agents under non-default environments: app > 1 (gravity every `app` actions: a trace can then contain
+    the same observation twice, the case the parallel backup must serialise), guideline scoring off / uniform
+    randomizer; Python ValueSim / ValueSimLP and the compiled C++ MCTSAgent.  Hash evaluator, small pools (GC)."""
+    ref_shims.install()
+    from pyTetris import Tetris
+    agent_mod = sys.modules["agents.cppmodule.agent"]
+
+    def ev_lp(obs):
+        a = np.asarray(obs).astype(np.int8)
+        v, var = hash_eval(a.reshape(a.shape[0], 20, 10))
+        return [v.tolist(), var.tolist()]
+    runs = [dict(name="ValueSim", sims=30, max_nodes=8000, seed=61, max_moves=120, env=[2, 1, 1]),
+            dict(name="ValueSimLP", sims=25, max_nodes=8000, seed=62, max_moves=120, env=[3, 0, 0]),
+            dict(name="MCTSAgent", sims=30, max_nodes=8000, seed=63, max_moves=160, env=[2, 0, 1])]
+    out = []
+    for r in runs:
+        app, scoring, randomizer = r["env"]
+        ref_shims.srand(1)
+        if r["name"] == "MCTSAgent":
+            agent = agent_mod.MCTSAgent(r["sims"], r["max_nodes"], True, 0.999, False, ev_lp, 0, True)
+        else:
+            agent = ref_shims.make_agent(r["name"], r["sims"], max_nodes=r["max_nodes"], evaluator=hash_eval,
+                                         env_args=((20, 10), app, scoring, randomizer))
+        game = Tetris((20, 10), app, scoring, randomizer, r["seed"])
+        agent.update_root(game)
+        moves = []
+        while len(moves) < r["max_moves"]:
+            a = int(agent.play())
+            stats = agent.get_stats().astype("<f4").tobytes().hex() if hasattr(agent, "get_stats") else ""
+            game.play(a)
+            agent.update_root(game)
+            moves.append([a, int(game.score), int(game.line_clears), stats])
+            if game.end:
+                game.reset()
+                agent.update_root(game)
+        out.append(dict(r, moves=moves))
+        print(r["name"], r["env"], "moves", len(moves), "final score", moves[-1][1], "lines", moves[-1][2], file=sys.stderr)
+    with open(os.path.join(OUT, "ref_agents_env.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -407,6 +449,8 @@ if __name__ == "__main__":
         gen_online()
     if "online_py" in which:
         gen_online_py()
+    if "agents_env" in which:
+        gen_agents_env()
     if "agents" in which:
         if params is None:
             params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]

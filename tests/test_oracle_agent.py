@@ -139,3 +139,31 @@ def test_store_nodes_matches_reference_python_agents(oracle, golden_dir, idx):
             a.update_root(g)
     assert len(got) >= 3 and got == r["harvests"]
     a.close()
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_agent_oracle_replays_reference_other_environments(oracle, golden_dir, idx):
+    """tests/golden/ref_agents_env.json: ValueSim (app 2, scoring 1, uniform randomizer), ValueSimLP (app 3) and the
+    compiled C++ MCTSAgent (app 2, uniform randomizer) of the reference on the oracle engine: with gravity every `app`
+    actions a trace can hold the same observation twice, the case where the backup must not be reordered."""
+    with open(os.path.join(golden_dir, "ref_agents_env.json")) as f:
+        r = json.load(f)[idx]
+    app, scoring, randomizer = r["env"]
+    cpp = r["name"] == "MCTSAgent"
+    g = oracle.Game(app, scoring, randomizer, r["seed"])
+    a = oracle.Agent(2 if cpp else KIND[r["name"]], max_nodes=r["max_nodes"], app=app, scoring=scoring,
+                     randomizer=randomizer, cpp_occupied=cpp)
+    a.update_root(g)
+    for i, (act, score, lines, stats_hex) in enumerate(r["moves"]):
+        got = a.play(r["sims"])
+        assert a.error == 0
+        assert got == act, (i, got, act)
+        if stats_hex:
+            assert a.stats().astype("<f4").tobytes().hex() == stats_hex, i
+        g.play(got)
+        a.update_root(g)
+        assert (g.score, g.line_clears) == (score, lines), i
+        if g.end:
+            g.reset()
+            a.update_root(g)
+    a.close()
