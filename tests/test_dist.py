@@ -87,3 +87,55 @@ def test_render_observations_matches_oracle(oracle):
         ref.append(g.getState())
     out = render_observations(torch.from_numpy(np.stack(keys))).numpy().reshape(-1, 20, 10)
     assert np.array_equal(out, np.stack(ref).astype(np.float32))
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from tetris_mcts_amd import train as T
+    from tetris_mcts_amd.model import Net
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net, data = _dp_setup()
+    gen = torch.Generator().manual_seed(1234)       # the same on both ranks: both draw the same half batch
+    res = T.train_data(net, T.Yogi(net.parameters(), lr=1e-3, eps=1e-3), data, batch_size=32, iters_per_val=4, max_iters=8,
+                       generator=gen, log=False)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    q.put((rank, flat.numpy(), res["iters"], res["best_validation"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dp_setup():
+    from tetris_mcts_amd.model import Net
+    torch.manual_seed(0)
+    net = Net()
+    g = torch.Generator().manual_seed(5)
+    n = 200
+    data = [torch.randint(-1, 2, (n, 1, 20, 10), generator=g).float(), torch.rand(n, 1, generator=g) * 50,
+            torch.rand(n, 1, generator=g) * 100 + 1, torch.randint(1, 30, (n, 1), generator=g).float()]
+    return net, data
+
+
+def test_data_parallel_training_gloo_world2():
+    """train_data with two ranks: each takes half of every batch, gradients are averaged by one all-reduce, the replicas
+    end bit-identical.  With the same sampling seed on both ranks the two halves coincide, so the averaged gradient is
+    the half-batch gradient and the run must equal a single process training with batch_size 16 and that seed."""
+    from tetris_mcts_amd import train as T
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1].tobytes() == res[1][1].tobytes() and res[0][2:] == res[1][2:]
+    net, data = _dp_setup()
+    single = T.train_data(net, T.Yogi(net.parameters(), lr=1e-3, eps=1e-3), data, batch_size=16, iters_per_val=4, max_iters=8,
+                          generator=torch.Generator().manual_seed(1234), log=False)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    assert single["iters"] == res[0][2]
+    assert np.array_equal(flat, res[0][1])

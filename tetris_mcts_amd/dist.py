@@ -3,7 +3,8 @@
 The reference has no collective at all (replicas write separate files, cycle.sh:69-73).  Games are independent
 (every agent owns its tree, agents/agent.py:58-88), so rank r simply owns games [r*G/P, (r+1)*G/P) with private
 pools and RNG streams.  The only exchange is the all-gather of the (state, TD-target) training tuples that GC
-harvests (ValueSim.store_nodes, ValueSim.py:122-159), so every rank can train the same replica on the union.
+harvests (ValueSim.store_nodes, ValueSim.py:122-159), so every rank can train the same replica on the union
+(train.train_data then splits each batch over the ranks and averages the gradients with one all-reduce per iteration).
 Backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 import torch

@@ -79,7 +79,9 @@ class Model_VV:
 
         def save():
             best["model"] = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
-            self.save(verbose=False)
+            from . import dist as tdist
+            if tdist.rank() == 0:      # replicas are identical: one checkpoint file, written by rank 0
+                self.save(verbose=False)
 
         def load():
             self.model.load_state_dict(best["model"])

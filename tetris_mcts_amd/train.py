@@ -94,9 +94,18 @@ def validation_loss(net, data, weighted, chunk=1024):
 def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validation_fraction=0.1,
                sample_replacement=True, oversampling=False, weighted=True, early_stopping=True, early_stopping_patience=10,
                early_stopping_threshold=1.0, shuffle=False, max_iters=100000, grad_clip=0.0, save=None, load=None,
-               generator=None, log=True):
+               generator=None, log=True, data_parallel=True, group=None):
     """data = [states f32 [n,1,20,10], values [n,1], variances [n,1], weights [n,1]] (device tensors).
-    save() / load() persist and restore the best weights (the reference goes through its checkpoint file)."""
+    save() / load() persist and restore the best weights (the reference goes through its checkpoint file).
+
+    With torch.distributed initialised and more than one rank (every rank holding the same data and the same weights, as
+    after dist.all_gather_tuples), `data_parallel` splits each batch: a rank draws batch_size / world samples of its
+    own, the flattened gradients (1.9 MB) are averaged with one all-reduce per iteration, and every rank takes the same
+    optimizer step - the replicas stay bit-identical.  Validation runs on every rank (same numbers, same stopping)."""
+    import torch.distributed as tdist
+    world = tdist.get_world_size(group) if (data_parallel and tdist.is_available() and tdist.is_initialized()) else 1
+    if world > 1:
+        batch_size = max(1, batch_size // world)
     n = data[0].shape[0]
     n_val = int(n * validation_fraction)
     data = list(data)
@@ -123,6 +132,15 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
         optimizer.zero_grad(set_to_none=True)
         loss, _ = batch_loss(net, [d[idx] for d in train], weighted)
         loss.backward()
+        if world > 1:
+            grads = [p.grad for p in net.parameters() if p.grad is not None]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            tdist.all_reduce(flat, group=group)
+            flat /= world
+            off = 0
+            for g in grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
         # 2-norm over all parameter gradients (model.py:87-95), reported in the log line the dashboards parse
         g_norm_avg += torch.sqrt(sum((p.grad.detach() ** 2).sum() for p in net.parameters() if p.grad is not None))
         if grad_clip > 0:
@@ -146,6 +164,9 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
                             save()
                 else:
                     fails += 1
+            if world > 1:      # the logged training loss is the mean over ranks (the gradient norm already is global)
+                tdist.all_reduce(loss_avg, group=group)
+                loss_avg /= world
             if log:
                 print("Iteration:{:7d}  training loss:{:6.4f}  validation loss:{:6.4f}±{:6.4f}  gradient norm:{:6.3f}    {}"
                       .format(it + 1, float(loss_avg) / iters_per_val, vmean, vstd, float(g_norm_avg) / iters_per_val, mark),
