@@ -113,7 +113,7 @@ class ReplayMemory:
     # ---- store_nodes (agent.cpp:777-816); the min_visit / end filter already ran on the device, at GC ----
     def store(self, keys, stats):
         n, space = int(keys.shape[0]), self.memory_size - self.memory_index
-        if n == 0:
+        if n == 0 or space <= 0:      # (a full memory at entry cannot happen in the reference: every policy empties or trims it)
             return
         if self.policy != 0:
             take = min(n, space)          # the reference's loop stops at the tuple that fills the memory
