@@ -23,13 +23,14 @@ extern "C" {
 #define TM_NACT 7
 #define TM_GAME_DW 16      /* packed game, ENGINE_SPEC.md section 2 (64 bytes) */
 #define TM_OBS_DW 12       /* packed observation, ENGINE_SPEC.md section 7 (48 bytes) */
-#define TM_REC_DW 24       /* node record (96 bytes): 7 x (child, obs, score bits) unique children in selection order,
-                              then TM_REC_HDR, TM_REC_OBS, TM_REC_SCORE; see DESIGN.md "node store" */
-#define TM_REC_HDR 21      /* bits 0-2 number of unique children, bit 24 game ended, bit 25 expanded */
-#define TM_REC_OBS 22      /* node_to_obs */
-#define TM_REC_SCORE 23    /* float32 score of the node's game */
+#define TM_REC_DW 32       /* node record (128 bytes = one cache line): eight 16-byte pieces.  Pieces 0..6 = the node's unique
+                              children in selection order: (child, obs, child score bits, own score bits); piece 7 =
+                              (0, TM_REC_OBS, TM_REC_SCORE, TM_REC_HDR); see DESIGN.md "node store" */
+#define TM_REC_OBS 29      /* node_to_obs */
+#define TM_REC_SCORE 30    /* float32 score of the node's game */
+#define TM_REC_HDR 31      /* bits 0-2 number of unique children, bit 24 game ended, bit 25 expanded */
 #define TM_KIDS_DW 8       /* raw children row: child[7] in action order + pad */
-#define TM_GS_DW 32        /* per-game control block */
+#define TM_GS_DW 64        /* per-game control block */
 #define TM_LEAF_DW 32      /* per-game leaf hand-off between the front and back halves of a simulation */
 #define TM_VALUENET_PARAMS 478342
 #define TM_VALUENET_SCRATCH 9728       /* floats of scratch per state, tm_valuenet_forward_plain */
@@ -44,9 +45,20 @@ enum {
     TM_GS_TRACE_SUM, /* sum of trace lengths over all simulations (for bytes/simulation accounting) */
     TM_GS_N_EVAL,    /* leaf states handed to the evaluator */
     TM_GS_N_POOL_RESET, /* tm_pool_reset calls that hit this game */
+    TM_GS_MAX_TRACE,    /* longest trace of any simulation so far */
     TM_GS_CYC_BACK = 20, TM_GS_CYC_SELECT, TM_GS_CYC_EXPAND, /* shader cycles of the last simulation's phases */
     TM_GS_CYC_TAIL,      /* duration of the last GC in units of 16 cycles; +1: nodes reachable at that GC */
-    TM_GS_LOW_NODE = 26, TM_GS_LOW_OBS   /* lowest node / observation index ever allocated (GC skips untouched entries) */
+    TM_GS_N_DROPPED = 25, /* replay tuples a GC could not store because the harvest buffer was full (drain it more often) */
+    TM_GS_LOW_NODE = 26, TM_GS_LOW_OBS,  /* lowest node / observation index ever allocated (GC skips untouched entries) */
+    /* resumable garbage collection (a game that collects does not simulate in that launch) */
+    TM_GS_GC_PHASE = 32, /* 0 none, 1 requested, 2 marking, 3 clearing the tables, 4 sweeping, 5 re-inserting */
+    TM_GS_GC_CURSOR, TM_GS_GC_TAIL, TM_GS_GC_NFREE, TM_GS_GC_ONFREE,
+    TM_GS_GC_CYC16,      /* cycles/16 spent so far in the collection in progress */
+    TM_GS_GC_SLICES,     /* launches that ran a slice of a collection (all collections) */
+    TM_GS_GC_RETRY,      /* the suspended expansion has already been through a collection */
+    /* per-move simulation quota: tm_move_begin adds `sims` to the target; a launch starts a simulation for a game only
+       while started < target, so games that lost launches to a collection catch up in extra launches (tm_sims_remaining) */
+    TM_GS_SIM_TARGET = 40, TM_GS_SIM_STARTED
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
@@ -76,11 +88,13 @@ typedef struct tm_store {
     int32_t min_visits_to_store; /* ValueSim.py:14 / ValueSimLP.py:11 */
     int32_t online;       /* harvest replay tuples on GC (ValueSim.py:109-115) */
     int32_t replay_cap;   /* capacity (tuples) of the replay buffer */
+    int32_t gc_slice_cycles; /* shader cycles a collecting game spends per launch before it yields (0: collect to completion) */
     double gamma;
     /* node store, per game contiguous */
-    uint32_t *node_rec;   /* [G][N][24] 7 x (child, obs, score) unique children in selection order, hdr, self_obs, self_score */
+    uint32_t *node_rec;   /* [G][N][32] 7 x (child, obs, score, own score) unique children in selection order, then (0, self_obs, self_score, hdr) */
     uint32_t *node_game;  /* [G][N][16] packed game */
-    uint32_t *obs_stat;   /* [G][N][4]  visit(i32), value(f32), variance(f32), end(u32) */
+    uint32_t *obs_stat;   /* [G][N][4]  visit (bits 0-30) | end << 31, value(f32), variance(f32), sqrtf(variance / (float)visit)
+                             (the exploration term of policy_clt, core.h:98, evaluated when the statistics change) */
     uint32_t *obs_key;    /* [G][N][12] packed observation */
     uint64_t *node_tab;   /* [G][cap]   (hash>>32)<<32 | node index ; index 0 = empty */
     uint64_t *obs_tab;    /* [G][cap] */
@@ -123,10 +137,35 @@ int tm_env_info(const tm_store *s, int32_t *out /* [G][8]: end, score, lines, co
 
 /* tree agent */
 int tm_update_root(const tm_store *s, void *stream);                                    /* agent.update_root(game) */
+/* One move of every game = tm_move_begin(sims), then launches of tm_sim_step(BACKUP|FRONT) each followed by the leaf
+ * evaluator, until tm_sims_remaining reports 0: a launch starts a new simulation for a game only while the game has
+ * quota left, backs up its pending one, or - when the game's node pool ran dry - runs one slice of its garbage
+ * collection instead (s->gc_slice_cycles), so `sims` launches + 1 are enough unless a game collected in this move. */
+int tm_move_begin(const tm_store *s, int sims, void *stream);
+int tm_sims_remaining(const tm_store *s, int32_t *out /* device int: max over games of launches still needed */, void *stream);
 #define TM_SIM_BACKUP 1  /* finish the pending simulation: backup with eval_v/eval_var */
 #define TM_SIM_FRONT 2   /* start one: select, expand, post evaluation requests into eval_obs */
 int tm_sim_step(const tm_store *s, int flags, void *stream);
 int tm_eval_render(const tm_store *s, int8_t *out /* [G*eval_slots][200] */, void *stream);
+
+/* The store of games [first, first+n) of *s (every array is per game contiguous: a slice is the same struct with
+ * offset pointers).  Sub-batches of one process, shards of a multi-GPU job. */
+int tm_store_slice(const tm_store *s, int first, int n, tm_store *out);
+
+/* Native driver of one move's search = the reference's `for i in range(sims)` loop (agents/ValueSim.py:76-94,
+ * agents/agent.py:147-150, agent.cpp:407-460) as a host launch loop.  The games are cut into n_sub sub-batches on
+ * their own HIP streams so that one sub-batch's tree kernel runs under another's value-net kernels; results per game do
+ * not depend on n_sub.  tm_search_run returns when all `sims` simulations of every game are complete (it issues the
+ * catch-up launches of games that collected garbage, tm_sims_remaining).  vn_params == NULL: no evaluator launches
+ * (TM_KIND_VANILLA).  vn_scratch: n_games * eval_slots * TM_VALUENET_SCRATCH_MFMA floats.  ev_every > 0: HIP events
+ * around every ev_every-th simulation of sub-batch 0 (on the stream it runs on), read back by tm_search_stats:
+ * out = {runs, tree launches, catch-up launches, timed samples, sum tree-kernel ms, sum value-net ms, n_sub}. */
+typedef struct tm_search tm_search;
+int tm_search_create(tm_search **out, const tm_store *s, int n_sub, int ev_every);
+void tm_search_destroy(tm_search *h);
+int tm_search_run(tm_search *h, int sims, const float *vn_params, const float *vn_prepared, float *vn_scratch,
+                  void *stream);
+int tm_search_stats(tm_search *h, double *out, int n, int reset);
 int tm_root_stats(const tm_store *s, float *stats /* [G][3][7] */, int32_t *action /* [G] */, void *stream);
 /* one game's tree in the reference's array layout (agents/agent.py:58-88), for inspection and tests */
 int tm_export_game(const tm_store *s, int game, int32_t *child /* [N][7] */, float *score, int32_t *n_to_o,

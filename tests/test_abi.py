@@ -33,8 +33,9 @@ def test_store_layout_matches_ctypes_mirror():
     out = (C.c_int * 8)()
     n = L.lib().tm_store_layout(out, 8)
     T = L.TmStore
-    assert list(out)[:n] == [C.sizeof(T), T.gamma.offset, T.node_rec.offset, T.nq_table.offset, T.replay_count.offset,
-                            T.mt_state.offset, T.node_child.offset]
+    assert n == 8 and list(out)[:n] == [C.sizeof(T), T.gamma.offset, T.node_rec.offset, T.nq_table.offset,
+                                        T.replay_count.offset, T.mt_state.offset, T.node_child.offset,
+                                        T.gc_slice_cycles.offset]
 
 
 def test_norm_quantile_table_is_the_reference_formula(oracle):

@@ -143,7 +143,7 @@ def test_full_size_batch_properties():
     # each simulation passes through the root exactly once: root observation visits == sims
     root = gs[:, 0]
     rec = st.t["node_rec"][torch.arange(G, device="cuda"), torch.as_tensor(root, device="cuda").long()]
-    root_obs = rec[:, 22].long()
+    root_obs = rec[:, 29].long()
     visits = st.t["obs_stat"][torch.arange(G, device="cuda"), root_obs, 0].cpu().numpy()
     assert (visits == sims).all()
     # the unique children of the root absorb all but the first simulation

@@ -17,7 +17,7 @@ class TmStore(C.Structure):
     _fields_ = [
         ("n_games", i32), ("max_nodes", i32), ("table_cap", i32), ("max_trace", i32), ("eval_slots", i32),
         ("nq_size", i32), ("app", i32), ("scoring", i32), ("randomizer", i32), ("low", i32), ("kind", i32),
-        ("min_visits_to_store", i32), ("online", i32), ("replay_cap", i32), ("gamma", f64),
+        ("min_visits_to_store", i32), ("online", i32), ("replay_cap", i32), ("gc_slice_cycles", i32), ("gamma", f64),
         ("node_rec", vp), ("node_game", vp), ("obs_stat", vp), ("obs_key", vp), ("node_tab", vp), ("obs_tab", vp),
         ("free_node", vp), ("free_obs", vp), ("gs", vp), ("rng", vp), ("env_game", vp), ("env_line_stats", vp),
         ("trace", vp), ("leaf", vp), ("eval_obs", vp), ("eval_v", vp), ("eval_var", vp), ("nq_table", vp),
@@ -36,6 +36,8 @@ SYMBOLS = {
     "tm_env_info": [C.POINTER(TmStore), vp, vp],
     "tm_update_root": [C.POINTER(TmStore), vp],
     "tm_sim_step": [C.POINTER(TmStore), i32, vp],
+    "tm_move_begin": [C.POINTER(TmStore), i32, vp],
+    "tm_sims_remaining": [C.POINTER(TmStore), vp, vp],
     "tm_eval_render": [C.POINTER(TmStore), vp, vp],
     "tm_root_stats": [C.POINTER(TmStore), vp, vp, vp],
     "tm_export_game": [C.POINTER(TmStore), i32, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -48,6 +50,10 @@ SYMBOLS = {
     "tm_valuenet_forward": [vp, vp, vp, i32, vp, vp, vp, vp],
     "tm_valuenet_forward_plain": [vp, vp, i32, vp, vp, vp, vp],
     "tm_valuenet_forward_requests": [vp, vp, C.POINTER(TmStore), vp, vp],
+    "tm_store_slice": [C.POINTER(TmStore), i32, i32, C.POINTER(TmStore)],
+    "tm_search_create": [C.POINTER(vp), C.POINTER(TmStore), i32, i32],
+    "tm_search_run": [vp, i32, vp, vp, vp, vp],
+    "tm_search_stats": [vp, vp, i32, i32],
 }
 
 _lib = None
@@ -70,6 +76,7 @@ def lib():
         L.tm_fill_norm_quantile.argtypes, L.tm_fill_norm_quantile.restype = [vp, i32], None
         L.tm_version.argtypes, L.tm_version.restype = [], C.c_char_p
         L.tm_store_layout.argtypes, L.tm_store_layout.restype = [vp, i32], i32
+        L.tm_search_destroy.argtypes, L.tm_search_destroy.restype = [vp], None
         _lib = L
     return _lib
 

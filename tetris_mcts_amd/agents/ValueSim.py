@@ -41,6 +41,9 @@ class ValueSim(TreeAgent):
         else:
             self.model.inference_device(states, v_out, var_out)
 
+    def search_model(self):
+        return self.model if (self.evaluator is None and self.model.backend == "hip") else False
+
     def evaluate_requests(self):
         if self.evaluator is None and self.model.backend == "hip":
             self.model.inference_requests(self.store)   # observations rendered inside the conv kernel
@@ -93,6 +96,5 @@ class ValueSim(TreeAgent):
         res = self.model.train_data(data, **opts)
         self.model.training(False)
         self._memory = None
-        self._graph = None    # weights changed: a captured graph would still be valid (same buffers), prepared streams are refreshed lazily
         print("Training complete.", file=stderr, flush=True)
         return res

@@ -75,5 +75,4 @@ class ValueSimC(ValueSim):
         opts.update(train_kwargs)
         res = self.model.train_data([state[:d_size], value[:d_size], variance[:d_size], visit[:d_size]], **opts)
         self.model.training(False)
-        self._graph = None
         return res

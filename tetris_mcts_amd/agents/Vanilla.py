@@ -29,5 +29,8 @@ class Vanilla(TreeAgent):
             states = [random.Random(base + g).getstate() for g in range(self.n_games)]
         self.store.set_python_random_states(states)
 
+    def search_model(self):
+        return None   # rollouts happen inside the tree kernel: the native loop launches no evaluator
+
     def evaluate_requests(self):
-        pass   # rollouts happen inside the tree kernel; there is nothing to evaluate
+        pass

@@ -25,17 +25,6 @@ class Agent:
     def get_prob(self):
         raise NotImplementedError('get_action not implemented')
 
-    def get_value_and_variance(self, node=None):
-        """Root observation's (value, variance) (agents/agent.py:195-204); only node=None (the root) is supported."""
-        if node is not None:
-            raise NotImplementedError("only the root is addressable on the device store")
-        s = self.store
-        g = torch.arange(self.n_games, device=s.device)
-        root = s.t["gs"][:, st.GS["ROOT"]].long()
-        o = s.t["node_rec"][g, root, 22].long()
-        vv = s.t["obs_stat"][g, o, 1:3].view(torch.float32).cpu().numpy()
-        return (vv[0, 0], vv[0, 1]) if self.n_games == 1 else (vv[:, 0], vv[:, 1])
-
     def update_root(self, game):
         raise NotImplementedError('update_root not implemented')
 
@@ -49,7 +38,8 @@ class TreeAgent(Agent):
 
     def __init__(self, sims=100, max_nodes=500000, env=None, env_args=None, node_saver=None, projection=True,
                  min_visits=30, n_games=None, gamma=0.999, online=False, min_visits_to_store=10, replay_cap=0,
-                 max_trace=1024, nq_size=1 << 20, use_graph=True, reset_on_pool_exhaustion=True, **kwargs):
+                 max_trace=1024, nq_size=1 << 20, reset_on_pool_exhaustion=True, n_sub=1, ev_every=0,
+                 gc_slice_cycles=150000, **kwargs):
         super().__init__(**kwargs)
         if not projection:
             raise NotImplementedError("projection=False is broken in the reference itself (ValueSim.py:73-74)")
@@ -63,18 +53,18 @@ class TreeAgent(Agent):
         self.n_games = n_games
         self._store_kwargs = dict(kind=self.kind, env_args=self.env_args, gamma=gamma, low=self.low, online=online,
                                   min_visits_to_store=min_visits_to_store, replay_cap=replay_cap, max_trace=max_trace,
-                                  nq_size=nq_size)
+                                  nq_size=nq_size, gc_slice_cycles=gc_slice_cycles)
+        self.n_sub, self.ev_every = int(n_sub), int(ev_every)
         self.store = None
         self.reset_on_pool_exhaustion = reset_on_pool_exhaustion
         self._pending_pool_reset = None
-        self.use_graph = use_graph
-        self._graph = None
         self.stats = None
         if n_games is not None:
             self._build(n_games)
 
     def _build(self, n_games):
         self.n_games = int(n_games)
+        self.n_sub = max(1, min(self.n_sub, self.n_games // 4))     # a sub-batch is at least one workgroup of the tree kernel
         self.store = st.TreeStore(self.n_games, self.max_nodes, **self._store_kwargs)
 
     # ---- evaluation hook (the `evaluator` callable of MCTSAgent, agent.cpp:396-405) ----
@@ -88,32 +78,29 @@ class TreeAgent(Agent):
         states = s.render_eval()
         self.evaluate(states, s.t["eval_v"], s.t["eval_var"])
 
-    def _sim_body(self):
-        self.store.sim_step(st.SIM_BACKUP | st.SIM_FRONT)
-        self.evaluate_requests()
+    def search_model(self):
+        """The model whose HIP value net the native launch loop (search.hip) evaluates leaves with; False = this agent's
+        evaluator is a Python callable, so the loop runs here instead."""
+        return False
 
     def mcts(self, sims):
+        """`sims` simulations for every game (TreeAgent.play -> self.mcts(self.root, self.sims), agents/agent.py:147-150).
+        A launch starts a simulation only for games with quota left; a game that collects garbage loses launches and
+        catches up at the end (store.sims_remaining)."""
         s = self.store
-        if self.use_graph and self._graph is None:
-            # warm up once eagerly (lazy initialisation inside torch / MIOpen must not be captured)
-            done = 0
-            if sims > 0:
-                self._sim_body()
-                done = 1
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._sim_body()
-            self._graph = g
-            for _ in range(sims - done):
-                g.replay()
-        elif self.use_graph:
-            for _ in range(sims):
-                self._graph.replay()
-        else:
-            for _ in range(sims):
-                self._sim_body()
-        s.sim_step(st.SIM_BACKUP)
+        model = self.search_model()
+        if model is not False:
+            s.search(sims, model, n_sub=self.n_sub, ev_every=self.ev_every)
+            return
+        both = st.SIM_BACKUP | st.SIM_FRONT
+        s.move_begin(sims)
+        s.sim_step(both)
+        todo = sims
+        while todo > 0:
+            for _ in range(todo):
+                self.evaluate_requests()
+                s.sim_step(both)
+            todo = s.sims_remaining()
 
     def play(self):
         self.mcts(self.sims)
@@ -160,7 +147,7 @@ class TreeAgent(Agent):
         s = self.store
         g = torch.arange(self.n_games, device=s.device)
         root = s.t["gs"][:, st.GS["ROOT"]].long()
-        o = s.t["node_rec"][g, root, 22].long()
+        o = s.t["node_rec"][g, root, 29].long()
         vv = s.t["obs_stat"][g, o, 1:3].view(torch.float32).cpu().numpy()
         return (vv[0, 0], vv[0, 1]) if self.n_games == 1 else (vv[:, 0], vv[:, 1])
 

@@ -19,12 +19,6 @@
 namespace tmcts {
 
 constexpr int WPB = 4;  // wavefronts (games) per workgroup
-#ifdef TM_SMALL_LDS
-constexpr int NQ_LDS = 512;
-#else
-constexpr int NQ_LDS = 2048;
-#endif  // entries of nq_table mirrored in LDS (child-visit sums are mostly small)
-
 constexpr int TRACE_LDS = 64;   // trace entries buffered in LDS before a coalesced flush
 struct WaveLds {
     uint32_t slots[8][GAME_DW];  // 0..6 successor games, 7 the parent
@@ -57,34 +51,30 @@ __device__ inline int mt_randint7(MtLds& m) {
     return (int)r;
 }
 
-struct GP {  // base pointers of one game
-    uint32_t *rec, *game, *stat, *okey, *kids;
-    uint64_t *ntab, *otab;
-    int32_t *fnode, *fobs, *gs, *leaf, *eval_obs;
-    uint32_t* trace;
-    float *eval_v, *eval_var;
+// Base pointers of one game, computed where they are used (g is wave-uniform, so each is a few scalar instructions):
+// holding all fifteen of them in scalar registers for the whole kernel made the tree walk's loop reload spilled ones.
+struct GP {
+    const tm_store& S;
+    int g;
+    __device__ __forceinline__ size_t n() const { return (size_t)S.max_nodes; }
+    __device__ __forceinline__ uint32_t* rec() const { return S.node_rec + (size_t)g * n() * TM_REC_DW; }
+    __device__ __forceinline__ uint32_t* kids() const { return S.node_child + (size_t)g * n() * TM_KIDS_DW; }
+    __device__ __forceinline__ uint32_t* game() const { return S.node_game + (size_t)g * n() * TM_GAME_DW; }
+    __device__ __forceinline__ uint32_t* stat() const { return S.obs_stat + (size_t)g * n() * 4; }
+    __device__ __forceinline__ uint32_t* okey() const { return S.obs_key + (size_t)g * n() * TM_OBS_DW; }
+    __device__ __forceinline__ uint64_t* ntab() const { return S.node_tab + (size_t)g * (size_t)S.table_cap; }
+    __device__ __forceinline__ uint64_t* otab() const { return S.obs_tab + (size_t)g * (size_t)S.table_cap; }
+    __device__ __forceinline__ int32_t* fnode() const { return S.free_node + (size_t)g * n(); }
+    __device__ __forceinline__ int32_t* fobs() const { return S.free_obs + (size_t)g * n(); }
+    __device__ __forceinline__ int32_t* gs() const { return S.gs + (size_t)g * TM_GS_DW; }
+    __device__ __forceinline__ int32_t* leaf() const { return S.leaf + (size_t)g * TM_LEAF_DW; }
+    __device__ __forceinline__ int32_t* eval_obs() const { return S.eval_obs + (size_t)g * S.eval_slots; }
+    __device__ __forceinline__ float* eval_v() const { return S.eval_v + (size_t)g * S.eval_slots; }
+    __device__ __forceinline__ float* eval_var() const { return S.eval_var + (size_t)g * S.eval_slots; }
+    __device__ __forceinline__ uint32_t* trace() const { return S.trace + (size_t)g * (size_t)S.max_trace * 4; }
 };
 
-__device__ __forceinline__ GP game_ptrs(const tm_store& S, int g) {
-    GP P;
-    size_t n = (size_t)S.max_nodes, gg = (size_t)g;
-    P.rec = S.node_rec + gg * n * TM_REC_DW;
-    P.kids = S.node_child + gg * n * TM_KIDS_DW;
-    P.game = S.node_game + gg * n * TM_GAME_DW;
-    P.stat = S.obs_stat + gg * n * 4;
-    P.okey = S.obs_key + gg * n * TM_OBS_DW;
-    P.ntab = S.node_tab + gg * (size_t)S.table_cap;
-    P.otab = S.obs_tab + gg * (size_t)S.table_cap;
-    P.fnode = S.free_node + gg * n;
-    P.fobs = S.free_obs + gg * n;
-    P.gs = S.gs + gg * TM_GS_DW;
-    P.leaf = S.leaf + gg * TM_LEAF_DW;
-    P.eval_obs = S.eval_obs + gg * S.eval_slots;
-    P.eval_v = S.eval_v + gg * S.eval_slots;
-    P.eval_var = S.eval_var + gg * S.eval_slots;
-    P.trace = S.trace + gg * (size_t)S.max_trace * 4;
-    return P;
-}
+__device__ __forceinline__ GP game_ptrs(const tm_store& S, int g) { return GP{S, g}; }
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ uint32_t shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
@@ -95,6 +85,45 @@ __device__ __forceinline__ float rl_f32(float v, int src) { return __uint_as_flo
 __device__ __forceinline__ uint32_t dpp_x1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t dpp_x2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t dpp_hm(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true); }
+// 16-byte load at a 32-bit byte offset from a wave-uniform base (global_load_dwordx4 v, v_off, s[base:base+1]): the per-game
+// arrays are < 4 GiB, so the walk needs one shift-add per address instead of 64-bit pointer arithmetic
+__device__ __forceinline__ uint4 ld16(const uint32_t* base, uint32_t byte_off) {
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// The same through a buffer resource (base, size) in four scalar registers: buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen.
+// An intrinsic call is one indivisible 16-byte load for the optimizer (a plain uint4 load was split, and the part only
+// one branch needs was sunk into that branch = a second memory round trip per tree level).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+    // wave-uniform by construction (one game per wave): pin base and size to scalar registers, or every load through the
+    // resource becomes a readfirstlane waterfall loop
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    const int nb = __builtin_amdgcn_readfirstlane((int)(uint32_t)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_ld16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t bperm_u32(int byte_addr, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)v);
+}
+// Wave-wide reductions of a value that is replicated inside each 8-lane group (one group per unique child): only the
+// strides 8, 16 and 32 are needed = row_shr:8, row_bcast:15 (rows 1, 3), row_bcast:31 (rows 2, 3); the result is in lane 63.
+__device__ __forceinline__ uint32_t group_sum_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return rl_u32(v, 63);
+}
+__device__ __forceinline__ int group_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     uint32_t lo = shfl_u32((uint32_t)v, src), hi = shfl_u32((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
@@ -206,7 +235,8 @@ __device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, u
     }
 }
 
-__device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane);
+__device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane);
+__device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, int lane, long long budget);
 
 __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, WaveLds& L, int g, int n, int lane,
                                       int& r_idx, int& r_obs) {
@@ -225,12 +255,12 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     int found = 0;
     uint32_t ins = 0;
     bool full = false;
-    if (uniq) found = table_find(P.ntab, mask, h, my, P.game, GAME_DW, ins, full);
+    if (uniq) found = table_find(P.ntab(), mask, h, my, P.game(), GAME_DW, ins, full);
     bool isnew = uniq && !found && !full;
     uint64_t need = __ballot(isnew);
     int cnt = __popcll(need);
-    int nfree = P.gs[TM_GS_NFREE_NODE];
-    if (__any(full)) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_TABLE); }
+    int nfree = P.gs()[TM_GS_NFREE_NODE];
+    if (__any(full)) { if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_TABLE); }
     if (cnt > nfree) {
         // Pool exhausted: the reference reclaims unreachable nodes at exactly this pop
         // (agents/agent.py:96-97).  Candidates before the exhausting one are inserted first, exactly as
@@ -241,14 +271,14 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         return;
     }
     int idx = found;
-    if (isnew) idx = P.fnode[nfree - 1 - __popcll(need & ((1ull << lane) - 1ull))];
+    if (isnew) idx = P.fnode()[nfree - 1 - __popcll(need & ((1ull << lane) - 1ull))];
     if (cnt) {
         // lowest index ever allocated (GC skips clearing what was never written)
         int lo = 0x7FFFFFFF;
         for (int b = 0; b < n; ++b) lo = min(lo, ((need >> b) & 1ull) ? (int)rl_u32((uint32_t)idx, b) : 0x7FFFFFFF);
-        if (lane == 0) { P.gs[TM_GS_NFREE_NODE] = nfree - cnt; if (lo < P.gs[TM_GS_LOW_NODE]) P.gs[TM_GS_LOW_NODE] = lo; }
+        if (lane == 0) { P.gs()[TM_GS_NFREE_NODE] = nfree - cnt; if (lo < P.gs()[TM_GS_LOW_NODE]) P.gs()[TM_GS_LOW_NODE] = lo; }
     }
-    table_insert_seq(P.ntab, mask, need, n, lane, h, ins, idx, L.misc);
+    table_insert_seq(P.ntab(), mask, need, n, lane, h, ins, idx, L.misc);
     // 3. observations of the new nodes (agents/agent.py:112-128)
     uint32_t* ok = L.okeys[act ? lane : 0];
     uint64_t ho = 0;
@@ -264,50 +294,50 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     int ofound = 0;
     uint32_t oins = 0;
     bool ofull = false;
-    if (ouniq) ofound = table_find(P.otab, mask, ho, ok, P.okey, OBS_DW, oins, ofull);
+    if (ouniq) ofound = table_find(P.otab(), mask, ho, ok, P.okey(), OBS_DW, oins, ofull);
     bool onew = ouniq && !ofound && !ofull;
     uint64_t oneed = __ballot(onew);
     int ocnt = __popcll(oneed);
-    int onfree = P.gs[TM_GS_NFREE_OBS];
+    int onfree = P.gs()[TM_GS_NFREE_OBS];
     int o = ofound;
-    if (onew) o = P.fobs[onfree - 1 - __popcll(oneed & ((1ull << lane) - 1ull))];
+    if (onew) o = P.fobs()[onfree - 1 - __popcll(oneed & ((1ull << lane) - 1ull))];
     if (ocnt) {
         int lo = 0x7FFFFFFF;
         for (int b = 0; b < n; ++b) lo = min(lo, ((oneed >> b) & 1ull) ? (int)rl_u32((uint32_t)o, b) : 0x7FFFFFFF);
-        if (lane == 0) { P.gs[TM_GS_NFREE_OBS] = onfree - ocnt; if (lo < P.gs[TM_GS_LOW_OBS]) P.gs[TM_GS_LOW_OBS] = lo; }
+        if (lane == 0) { P.gs()[TM_GS_NFREE_OBS] = onfree - ocnt; if (lo < P.gs()[TM_GS_LOW_OBS]) P.gs()[TM_GS_LOW_OBS] = lo; }
     }
-    table_insert_seq(P.otab, mask, oneed, n, lane, ho, oins, o, L.misc + 8);
+    table_insert_seq(P.otab(), mask, oneed, n, lane, ho, oins, o, L.misc + 8);
     if (onew) {
-        uint4* dst = reinterpret_cast<uint4*>(P.okey + (size_t)o * OBS_DW);
+        uint4* dst = reinterpret_cast<uint4*>(P.okey() + (size_t)o * OBS_DW);
         dst[0] = make_uint4(ok[0], ok[1], ok[2], ok[3]);
         dst[1] = make_uint4(ok[4], ok[5], ok[6], ok[7]);
         dst[2] = make_uint4(ok[8], ok[9], ok[10], ok[11]);
         // visit, value, variance = 0 and obs_arrays['end'] (agents/agent.py:123): slots are initialised when they are
         // handed out, so the GC does not have to clear the key / record streams of everything it frees
-        *reinterpret_cast<uint4*>(P.stat + (size_t)o * 4) = make_uint4(0u, 0u, 0u, ok[11] & 0xFFu);
+        *reinterpret_cast<uint4*>(P.stat() + (size_t)o * 4) = make_uint4((ok[11] & 1u) << 31, 0u, 0u, 0u);
     }
     {   // same observation as an earlier new candidate
         int osrc = shfl_u32((uint32_t)o, odup);
         if (isnew && odup != lane) o = osrc;
     }
     if (isnew) {
-        uint4* dst = reinterpret_cast<uint4*>(P.game + (size_t)idx * GAME_DW);
+        uint4* dst = reinterpret_cast<uint4*>(P.game() + (size_t)idx * GAME_DW);
         dst[0] = make_uint4(my[0], my[1], my[2], my[3]);
         dst[1] = make_uint4(my[4], my[5], my[6], my[7]);
         dst[2] = make_uint4(my[8], my[9], my[10], my[11]);
         dst[3] = make_uint4(my[12], my[13], my[14], my[15]);
         // the whole record: no children yet (slot triples and raw child row zero), then hdr = end flag of the node's
         // game, node_to_obs, arrays['score'][idx] = game.score (float32)
-        static_assert(TM_REC_HDR == 21 && TM_REC_OBS == 22 && TM_REC_SCORE == 23 && TM_REC_DW == 24 && TM_KIDS_DW == 8,
+        static_assert(TM_REC_OBS == 29 && TM_REC_SCORE == 30 && TM_REC_HDR == 31 && TM_REC_DW == 32 && TM_KIDS_DW == 8,
                       "record layout");
         const uint4 z = make_uint4(0, 0, 0, 0);
-        uint4* r = reinterpret_cast<uint4*>(P.rec + (size_t)idx * TM_REC_DW);
-        r[0] = z; r[1] = z; r[2] = z; r[3] = z; r[4] = z;
-        r[5] = make_uint4(0u, ((my[11] >> 8) & 1u) << 24, (uint32_t)o, __float_as_uint((float)(int)my[14]));
-        uint4* kd = reinterpret_cast<uint4*>(P.kids + (size_t)idx * TM_KIDS_DW);
+        uint4* r = reinterpret_cast<uint4*>(P.rec() + (size_t)idx * TM_REC_DW);
+        r[0] = z; r[1] = z; r[2] = z; r[3] = z; r[4] = z; r[5] = z; r[6] = z;
+        r[7] = make_uint4(0u, (uint32_t)o, __float_as_uint((float)(int)my[14]), ((my[11] >> 8) & 1u) << 24);
+        uint4* kd = reinterpret_cast<uint4*>(P.kids() + (size_t)idx * TM_KIDS_DW);
         kd[0] = z; kd[1] = z;
     }
-    if (uniq && found) o = (int)P.rec[(size_t)found * TM_REC_DW + TM_REC_OBS];
+    if (uniq && found) o = (int)P.rec()[(size_t)found * TM_REC_DW + TM_REC_OBS];
     {
         int isrc = shfl_u32((uint32_t)idx, dup), osrc = shfl_u32((uint32_t)o, dup);
         if (act && dup != lane) { idx = isrc; o = osrc; }
@@ -319,11 +349,14 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
 // ---------------------------------------------------------------------------------------------------
 // expand (agents/agent.py:136-145): 7 successors of `leaf`, written into the leaf's record together
 // with the unique-child list of get_unique_child_obs (core.h:111-144).
-// Per-lane outputs for lane a < 7: child node / obs / score bits.  Returns false on pool exhaustion.
+// Returns false when the node pool ran dry at one of the seven pops: the successors before it are inserted and linked
+// (exactly the reference's state at the moment it calls remove_nodes, agents/agent.py:96-97), a collection is requested
+// (TM_GS_GC_PHASE = 1) and the caller suspends the simulation; once the collection is complete the expansion is simply
+// redone - the successors already inserted are transposition hits, the others pop from the rebuilt free list in order.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
-                                   uint32_t& hdr_out) {
-    if (lane < GAME_DW) L.slots[7][lane] = P.game[(size_t)leaf * GAME_DW + lane];
+                                   uint32_t self_sc /* float bits of the leaf's own score */, uint32_t& hdr_out) {
+    if (lane < GAME_DW) L.slots[7][lane] = P.game()[(size_t)leaf * GAME_DW + lane];
     wave_sync();
     for (int t = lane; t < 7 * GAME_DW; t += 64) L.slots[t >> 4][t & 15] = L.slots[7][t & 15];
     wave_sync();
@@ -351,9 +384,15 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
             int i1, o1;
             wave_new_nodes(S, P, L, g, 1, lane, i1, o1);
             if (i1 < 0) {
-                gc_wave(S, P, L, g, lane);
-                wave_new_nodes(S, P, L, g, 1, lane, i1, o1);
-                if (i1 < 0) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_POOL); i1 = 0; o1 = 0; }
+                if (!P.gs()[TM_GS_GC_RETRY]) {
+                    if (lane < GAME_DW) L.slots[0][lane] = keep;
+                    if (lane == 0) { P.gs()[TM_GS_GC_PHASE] = 1; P.gs()[TM_GS_GC_RETRY] = 1; }
+                    wave_sync();
+                    return false;
+                }
+                // the pool is exhausted although everything unreachable has just been reclaimed
+                if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_POOL);
+                i1 = 0; o1 = 0;
             }
             i1 = (int)rl_u32((uint32_t)i1, 0);
             o1 = (int)rl_u32((uint32_t)o1, 0);
@@ -362,14 +401,14 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
             if (lane == a) { out_idx = i1; out_o = o1; }
             // the reference links child[idx][a] right after each new_node (agent.py:145), which is what
             // makes earlier successors reachable for a later GC
-            if (lane == 0) P.kids[(size_t)leaf * TM_KIDS_DW + a] = (uint32_t)i1;
+            if (lane == 0) P.kids()[(size_t)leaf * TM_KIDS_DW + a] = (uint32_t)i1;
             wave_sync();
         }
         idx = out_idx;
         o = out_o;
     }
     uint32_t sbits = __float_as_uint((float)(int)L.slots[lane < 7 ? lane : 0][14]);
-    if (lane < 7) P.kids[(size_t)leaf * TM_KIDS_DW + lane] = (uint32_t)idx;    // raw children, action order
+    if (lane < 7) P.kids()[(size_t)leaf * TM_KIDS_DW + lane] = (uint32_t)idx;    // raw children, action order
     // get_unique_child_obs (core.h:126-142), evaluated once here because its inputs never change.  Lane a owns
     // action a: every lane scans the actions in order, finds the first action with its observation ("first") and,
     // from there on, keeps the strictly-greater score (the reference's replacement rule).  The first lane of each
@@ -396,13 +435,12 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
         const int nu = __popcll(lead_mask);
         const int slot = __popcll(lead_mask & ((1ull << lane) - 1ull));
         const uint32_t hdr = (uint32_t)nu | (1u << 25);
-        uint32_t* r = P.rec + (size_t)leaf * TM_REC_DW;
+        uint32_t* r = P.rec() + (size_t)leaf * TM_REC_DW;
         if (lane < 7) { L.misc[16 + lane] = 0; L.misc[24 + lane] = 0; L.misc[32 + lane] = 0; }
         wave_sync();
         if (leader) {
-            r[3 * slot] = best_c;
-            r[3 * slot + 1] = my_o;
-            r[3 * slot + 2] = __float_as_uint(best_s);
+            // (child, observation, child score, own score): the walk's lane group for this slot needs nothing else
+            reinterpret_cast<uint4*>(r)[slot] = make_uint4(best_c, my_o, __float_as_uint(best_s), self_sc);
             L.misc[16 + slot] = best_c;                 // slot-ordered copies for the evaluation requests
             L.misc[24 + slot] = my_o;
             L.misc[32 + slot] = __float_as_uint(best_s);
@@ -417,9 +455,18 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
 // ---------------------------------------------------------------------------------------------------
 // Welford update of one observation (core.h:248-257); fp64 arithmetic, fp32 storage, no contraction
 // ---------------------------------------------------------------------------------------------------
+// statistics record of an observation: visit | end << 31, value, variance and the exploration term of policy_clt
+// (core.h:98: sqrtf(variance / (float)visit), the same two correctly rounded float operations, evaluated here once
+// per update instead of once per child per tree level in the walk)
+__device__ __forceinline__ void store_stat(uint32_t* st, uint32_t old_x, int visit, float value, float variance) {
+    const float ratio = variance / (float)visit;
+    const float root = sqrtf(ratio);
+    *reinterpret_cast<uint4*>(st) = make_uint4((uint32_t)visit | (old_x & 0x80000000u), __float_as_uint(value),
+                                               __float_as_uint(variance), __float_as_uint(root));
+}
 __device__ __forceinline__ void welford_f64(uint32_t* st, double x, double var_in) {
     uint4 s = *reinterpret_cast<uint4*>(st);
-    int visit = (int)s.x;
+    int visit = (int)(s.x & 0x7FFFFFFFu);
     float value = __uint_as_float(s.y), variance = __uint_as_float(s.z);
     if (visit == 0) {
         value = (float)x;
@@ -431,14 +478,12 @@ __device__ __forceinline__ void welford_f64(uint32_t* st, double x, double var_i
         double prod = delta * delta2;
         variance = (float)((double)variance + (prod - (double)variance) / (double)(visit + 1));
     }
-    st[0] = (uint32_t)(visit + 1);
-    st[1] = __float_as_uint(value);
-    st[2] = __float_as_uint(variance);
+    store_stat(st, s.x, visit + 1, value, variance);
 }
 // agent.cpp:496-513: the carried value is a float
 __device__ __forceinline__ void welford_f32carry(uint32_t* st, float x, float var_in) {
     uint4 s = *reinterpret_cast<uint4*>(st);
-    int visit = (int)s.x;
+    int visit = (int)(s.x & 0x7FFFFFFFu);
     float value = __uint_as_float(s.y), variance = __uint_as_float(s.z);
     if (visit == 0) {
         value = x;
@@ -450,9 +495,7 @@ __device__ __forceinline__ void welford_f32carry(uint32_t* st, float x, float va
         double prod = delta * delta2;
         variance = (float)((double)variance + (prod - (double)variance) / (double)(visit + 1));
     }
-    st[0] = (uint32_t)(visit + 1);
-    st[1] = __float_as_uint(value);
-    st[2] = __float_as_uint(variance);
+    store_stat(st, s.x, visit + 1, value, variance);
 }
 
 // backup of the stored trace.  Entries are handled 64 at a time from the leaf end; the carried value
@@ -469,7 +512,7 @@ __device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lan
         int cnt = min(64, len - base);
         int i = len - 1 - base - lane;
         uint4 e = make_uint4(0, 0, 0, 0);
-        if (lane < cnt) e = reinterpret_cast<const uint4*>(P.trace)[i];
+        if (lane < cnt) e = reinterpret_cast<const uint4*>(P.trace())[i];
         double x = 0;
         float xf = 0;
         for (int j = 0; j < cnt; ++j) {
@@ -487,7 +530,7 @@ __device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lan
             }
         }
         if (lane < cnt) {
-            uint32_t* st = P.stat + (size_t)e.y * 4;
+            uint32_t* st = P.stat() + (size_t)e.y * 4;
             if (float_carry) welford_f32carry(st, xf, varf);
             else welford_f64(st, x, var0);
         }
@@ -500,9 +543,9 @@ __device__ inline void lane_backup_trace_seq(const tm_store& S, const GP& P, int
     double V = v0;
     float Vf = (float)v0;
     for (int i = len - 1; i >= 0; --i) {
-        uint4 e = reinterpret_cast<const uint4*>(P.trace)[i];
+        uint4 e = reinterpret_cast<const uint4*>(P.trace())[i];
         float sj = __uint_as_float(e.z);
-        uint32_t* st = P.stat + (size_t)e.y * 4;
+        uint32_t* st = P.stat() + (size_t)e.y * 4;
         if (float_carry) {
             Vf = Vf - sj;
             welford_f32carry(st, Vf, (float)var0);
@@ -523,9 +566,9 @@ __device__ inline bool trace_has_repeat(const GP& P, int lane, int len, const in
     bool rep = false;
     for (int base = 0; base < len; base += 64) {
         int i = base + lane;
-        uint32_t oi = (i < len) ? P.trace[(size_t)i * 4 + 1] : 0xFFFFFFFFu;
+        uint32_t oi = (i < len) ? P.trace()[(size_t)i * 4 + 1] : 0xFFFFFFFFu;
         for (int j = 0; j < len; ++j) {
-            uint32_t oj = P.trace[(size_t)j * 4 + 1];
+            uint32_t oj = P.trace()[(size_t)j * 4 + 1];
             if (i < len && j != i && oj == oi) rep = true;
         }
         for (int j = 0; j < n_extra; ++j)
@@ -538,10 +581,10 @@ __device__ inline bool trace_has_repeat(const GP& P, int lane, int len, const in
 // the back half of a simulation: ValueSim.py:83-94 / ValueSimLP.py:59-70 / agent.cpp:432-446,458
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L, int lane) {
-    const int len = P.gs[TM_GS_TRACE_LEN];
-    const int leaf_end = P.gs[TM_GS_LEAF_END];
-    const int k = P.gs[TM_GS_K_EVAL];
-    const int leaf_score = P.gs[TM_GS_LEAF_SCORE];
+    const int len = P.gs()[TM_GS_TRACE_LEN];
+    const int leaf_end = P.gs()[TM_GS_LEAF_END];
+    const int k = P.gs()[TM_GS_K_EVAL];
+    const int leaf_score = P.gs()[TM_GS_LEAF_SCORE];
     const int kind = S.kind;
     const bool fcarry = (kind == TM_KIND_CPPAGENT_LP || kind == TM_KIND_CPPAGENT);
     double v0 = 0, var0 = 0;
@@ -551,30 +594,27 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
         var0 = leaf_end ? 0.0 : 1e3;
     } else if (kind == TM_KIND_VALUESIM) {
         v0 = (double)leaf_score;   // Python int score + np.float32 v under numpy 1.17 = float64
-        if (!leaf_end) { v0 = v0 + (double)P.eval_v[0]; var0 = (double)P.eval_var[0]; }
+        if (!leaf_end) { v0 = v0 + (double)P.eval_v()[0]; var0 = (double)P.eval_var()[0]; }
     } else if (kind == TM_KIND_CPPAGENT) {
         float ls = (float)leaf_score;   // score[trace.back()] is a float array element
-        if (!leaf_end) { v0 = (double)(ls + P.eval_v[0]); var0 = (double)P.eval_var[0]; }
+        if (!leaf_end) { v0 = (double)(ls + P.eval_v()[0]); var0 = (double)P.eval_var()[0]; }
         else v0 = (double)ls;
     } else {
         // leaf-parallel: first-visit initialisation of the unique children, then the averaged target
-        if (S.app > 1) seq = trace_has_repeat(P, lane, len, P.leaf + 7, k);
+        if (S.app > 1) seq = trace_has_repeat(P, lane, len, P.leaf() + 7, k);
         if (k > 0) {
-            int co = (lane < k) ? P.leaf[7 + lane] : 0;
-            float cs = (lane < k) ? __int_as_float(P.leaf[14 + lane]) : 0.f;
+            int co = (lane < k) ? P.leaf()[7 + lane] : 0;
+            float cs = (lane < k) ? __int_as_float(P.leaf()[14 + lane]) : 0.f;
             uint4 st = make_uint4(0, 0, 0, 0);
-            if (lane < k) st = *reinterpret_cast<const uint4*>(P.stat + (size_t)co * 4);
+            if (lane < k) st = *reinterpret_cast<const uint4*>(P.stat() + (size_t)co * 4);
             float cval = __uint_as_float(st.y), cvar = __uint_as_float(st.z);
-            if (lane < k && st.x == 0) {
+            if (lane < k && (st.x & 0x7FFFFFFFu) == 0) {
                 // core.h:344-352 tests end[child node] with the never-written arrays['end'] (ValueSimLP.py:25):
                 // always false.  agent.cpp:538 tests end_obs[o].
-                bool e = (kind == TM_KIND_CPPAGENT_LP) ? (st.w & 1u) : false;
-                cval = e ? 0.f : P.eval_v[lane];
-                cvar = e ? 0.f : P.eval_var[lane];
-                uint32_t* dst = P.stat + (size_t)co * 4;
-                dst[0] = 1u;
-                dst[1] = __float_as_uint(cval);
-                dst[2] = __float_as_uint(cvar);
+                bool e = (kind == TM_KIND_CPPAGENT_LP) ? ((st.x >> 31) != 0) : false;
+                cval = e ? 0.f : P.eval_v()[lane];
+                cvar = e ? 0.f : P.eval_var()[lane];
+                store_stat(P.stat() + (size_t)co * 4, st.x, 1, cval, cvar);
             }
             double vt = 0, vart = 0;
             for (int i = 0; i < k; ++i) {
@@ -600,137 +640,166 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
         seq = trace_has_repeat(P, lane, len, nullptr, 0);
     if (seq) { if (lane == 0) lane_backup_trace_seq(S, P, len, v0, var0, fcarry); }
     else wave_backup_trace(S, P, lane, len, v0, var0, fcarry);
-    if (lane == 0) { P.gs[TM_GS_PENDING] = 0; P.gs[TM_GS_N_SIMS] += 1; }
+    if (lane == 0) { P.gs()[TM_GS_PENDING] = 0; P.gs()[TM_GS_N_SIMS] += 1; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// second stage of the front half: expansion of the leaf and the evaluation requests.  Runs right after the
+// walk, or again from the control block when the expansion had to wait for a collection.
+// ---------------------------------------------------------------------------------------------------
+template <bool VANILLA>
+__device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
+                                                  int leaf_end, uint32_t self_o, uint32_t self_sc) {
+    const long long tc0 = __builtin_readcyclecounter();
+    const int kind = S.kind;
+    int k_eval = 0;
+    if (!leaf_end) {
+        uint32_t lh;
+        if (!wave_expand(S, P, L, g, lane, leaf, self_sc, lh)) {
+            if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
+            if (lane == 0) P.gs()[TM_GS_PENDING] = 2;
+            return;
+        }
+        if (VANILLA) {
+            k_eval = 0;
+            if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
+        } else if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT) {
+            k_eval = 1;
+            if (lane == 0) P.eval_obs()[0] = (int)self_o;
+        } else {
+            // unique children of the freshly expanded leaf (ValueSimLP.py:55 / agent.cpp:424)
+            const int nu = (int)(lh & 7u);
+            k_eval = nu;
+            if (lane < 7) {
+                bool on = lane < nu;
+                P.leaf()[lane] = on ? (int)L.misc[16 + lane] : 0;
+                P.leaf()[7 + lane] = on ? (int)L.misc[24 + lane] : 0;
+                P.leaf()[14 + lane] = on ? (int)L.misc[32 + lane] : 0;
+                P.eval_obs()[lane] = on ? (int)L.misc[24 + lane] : 0;
+            }
+        }
+        if (lane == 0) P.gs()[TM_GS_N_EXPAND] += 1;
+    } else {
+        if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
+    }
+    if (lane == 0) {
+        int32_t* gs = P.gs();
+        gs[TM_GS_CYC_EXPAND] = (int)((long long)__builtin_readcyclecounter() - tc0);
+        gs[TM_GS_PENDING] = 1;
+        gs[TM_GS_GC_RETRY] = 0;
+        gs[TM_GS_K_EVAL] = k_eval;
+        gs[TM_GS_N_EVAL] += k_eval;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // the front half: select_trace_obs (core.h:167-224), then expansion and evaluation requests
 // ---------------------------------------------------------------------------------------------------
 template <bool VANILLA>
-__device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, const float* nq_lds, int g, int lane) {
+__device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, int g, int lane) {
     const long long tc_start = __builtin_readcyclecounter();
     uint32_t rs = (lane < 32) ? S.rng[(size_t)g * 32 + lane] : 0u;   // glibc rand() state word i in lane i
-    int rng_pos = P.gs[TM_GS_RNG_POS];
+    int rng_pos = P.gs()[TM_GS_RNG_POS];
     const int rng_pos0 = rng_pos;
-    int idx = P.gs[TM_GS_ROOT];
+    int idx = P.gs()[TM_GS_ROOT];
     int len = 0;
     uint32_t hdr = 0, self_o = 0;
     const int low = S.low;
     int nq_fallback = 0;
     bool overflow = false;
-    // Node record = 8 pieces of 3 dwords: pieces 0..6 are the unique children in selection order
-    // (child, observation, score), piece 7 is (header, own observation, own score).  Lane k < 8 holds piece k, so the
-    // children's fields are already in the lanes that evaluate them.  Per level ONE round of loads: the children's
-    // statistics (16 B, lanes 0..6) and, speculatively, the records of all unique children (lane 8t+k loads piece k
-    // of child t: one dwordx3 per lane) - whichever child is selected, its record is already in registers.
-    // Nothing is stored to global memory inside the walk (stores share the load counter on gfx9: a store per level
-    // would make every level wait for its acknowledgement); the trace goes through LDS and is flushed 64 entries at
-    // a time with coalesced 16-byte stores.
-    const int pf_t = lane >> 3, pf_k = lane & 7;
-    uint32_t dx = 0, dy = 0, dz = 0;
-    if (lane < 8) {
-        const uint32_t* p = P.rec + (size_t)idx * TM_REC_DW + 3 * lane;
-        dx = p[0]; dy = p[1]; dz = p[2];
-    }
+    // Node record = eight 16-byte pieces: pieces 0..6 are the unique children in selection order (child, observation,
+    // child score, own score), piece 7 is (0, own observation, own score, header).  The wave is eight 8-lane groups:
+    // every lane of group j holds piece j of the current node, so group j owns unique child j.  Per level ONE round
+    // of loads: lane (j, t) loads the statistics of observation j (16 B, the same address in the whole group) and,
+    // speculatively, piece t of child j's record - whichever child is selected, its record is already in registers
+    // and four ds_bpermute move piece j' of it into group j'.  Empty slots and group 7 carry child 0 / observation 0
+    // (the null entries, always valid addresses).  Nothing is stored to global memory inside the walk (stores share the
+    // load counter on gfx9); the trace goes through LDS and is flushed 64 entries at a time with coalesced stores.
+    const int grp = lane >> 3;
+    const uint32_t pc16 = (uint32_t)(lane & 7) * 16u;
+    const int grp4 = grp * 4;
+    const __amdgpu_buffer_rsrc_t rec_rs = make_rsrc(P.rec(), P.n() * (TM_REC_DW * 4u));
+    const __amdgpu_buffer_rsrc_t stat_rs = make_rsrc(P.stat(), P.n() * 16u);
+    uint4 cur = buf_ld16(rec_rs, (uint32_t)idx * (TM_REC_DW * 4u) + (uint32_t)grp * 16u);
     int flushed = 0;
     auto flush_trace = [&](int upto) {   // entries [flushed, upto) from LDS to global, 64 per pass
         for (int base = flushed; base < upto; base += 64) {
             int i = base + lane;
-            if (i < upto) reinterpret_cast<uint4*>(P.trace)[i] = L.tbuf[i - flushed];
+            if (i < upto) reinterpret_cast<uint4*>(P.trace())[i] = L.tbuf[i - flushed];
         }
         flushed = upto;
     };
+    // wave-uniform index into a table nobody writes: constant address space = one s_load_dword through the scalar cache
+    typedef const float __attribute__((address_space(4))) * const_f32_ptr;
+    const const_f32_ptr nqt = (const_f32_ptr)(uintptr_t)S.nq_table;
+    const int nq_size = S.nq_size, max_trace = S.max_trace;
     for (;;) {
-        hdr = rl_u32(dx, 7);
-        self_o = rl_u32(dy, 7);
-        uint32_t self_sc = rl_u32(dz, 7);
-        if (len >= S.max_trace) { overflow = true; break; }
+        if (len >= max_trace) { overflow = true; break; }
         if (len - flushed == TRACE_LDS) { wave_sync(); flush_trace(len); wave_sync(); }
-        if (lane == 0) L.tbuf[len - flushed] = make_uint4((uint32_t)idx, self_o, self_sc, 0u);
+        if (lane == 56) L.tbuf[len - flushed] = make_uint4((uint32_t)idx, cur.y, cur.z, 0u);   // group 7: own observation, own score
         len += 1;
-        const int nu = (int)(hdr & 7u);
-        if (nu == 0) break;
-        const bool on = lane < nu;
-        const uint32_t c = on ? dx : 0u, o = on ? dy : 0u;     // empty slots / other lanes read entry 0 (always valid)
-        const float sc = __uint_as_float(dz);
-        // loads of this level: statistics of my child observation; piece pf_k of unique child pf_t
-        const uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
-        uint32_t ct = shfl_u32(c, pf_t < 7 ? pf_t : 0);
-        ct = (pf_t < nu) ? ct : 0u;
-        const uint32_t* pp = P.rec + (size_t)ct * TM_REC_DW + 3 * pf_k;
-        const uint32_t px = pp[0], py = pp[1], pz = pp[2];
-        const int visit = on ? (int)st.x : 0;
+        const bool on = cur.x != 0u;
+        if (__ballot(on) == 0ull) break;          // no children: a leaf
+        // the loads of this level
+        const uint4 st = buf_ld16(stat_rs, cur.y * 16u);
+        const uint4 pf = buf_ld16(rec_rs, cur.x * (TM_REC_DW * 4u) + pc16);
+        const int visit = (int)(st.x & 0x7FFFFFFFu);
         const uint64_t lowmask = __ballot(on && visit < low);
         int sel;
         if (lowmask) {
             // check_low (core.h:65-77): a uniformly drawn under-visited child, libc rand()
-            int m = __popcll(lowmask);
-            uint32_t r = wave_rand(rs, rng_pos);
-            int kth = (int)(r % (uint32_t)m);
-            uint64_t mm = lowmask;
+            uint64_t mm = lowmask & 0x0101010101010101ull;      // one bit per group
+            const int m = __popcll(mm);
+            const uint32_t r = wave_rand(rs, rng_pos);
+            const int kth = (int)(r % (uint32_t)m);
             for (int t = 0; t < kth; ++t) mm &= mm - 1;
-            sel = __ffsll((long long)mm) - 1;
+            sel = (__ffsll((long long)mm) - 1) >> 3;
         } else {
-            // policy_clt (core.h:83-105): float arithmetic, one rounding per operation.
-            // n = sum of the children's visits: butterfly over the 8-lane group (lanes >= nu hold 0)
-            uint32_t ns = (uint32_t)visit;
-            ns += dpp_x1(ns);
-            ns += dpp_x2(ns);
-            ns += dpp_hm(ns);
-            const int n = (int)rl_u32(ns, 0);
+            // policy_clt (core.h:83-105): float arithmetic, one rounding per operation; the exploration term
+            // sqrtf(variance / (float)visit) was evaluated (with the same two operations) when the statistics changed.
+            const int n = (int)group_sum_u32(on ? (uint32_t)visit : 0u);     // n = sum of the children's visits
             float coeff;
-            if (n < NQ_LDS && n < S.nq_size) coeff = nq_lds[n];
-            else if (n < S.nq_size) coeff = S.nq_table[n];
+            if (n < nq_size) coeff = nqt[n];
             else { coeff = norm_quantile_dev((double)n); nq_fallback += 1; }
-            float value = __uint_as_float(st.y), variance = __uint_as_float(st.z);
-            float t1 = value + sc;
-            float val = t1 - __uint_as_float(self_sc);
-            float ratio = variance / (float)visit;
-            float root = sqrtf(ratio);
-            float prod = coeff * root;
-            float q = val + prod;
+            const float t1 = __uint_as_float(st.y) + __uint_as_float(cur.z);
+            const float val = t1 - __uint_as_float(cur.w);
+            const float prod = coeff * __uint_as_float(st.w);
+            const float q = val + prod;
             // first-max argmax with the reference's scan semantics (max_q = q_0; i >= 1 replaces only if q_i > max_q):
-            // a NaN at i >= 1 never wins, a NaN at 0 is never replaced; ties keep the lower index.
-            float bq = on ? q : -INFINITY;
-            if (bq != bq) bq = (lane == 0) ? INFINITY : -INFINITY;
-            uint32_t bi = (uint32_t)lane;
-#define TM_ARGMAX_STEP(X)                                                                 \
-            {                                                                             \
-                const float pq = __uint_as_float(X(__float_as_uint(bq)));                 \
-                const uint32_t pi = X(bi);                                                \
-                const bool take = (pq > bq) || (pq == bq && pi < bi);                     \
-                bq = take ? pq : bq;                                                      \
-                bi = take ? pi : bi;                                                      \
-            }
-            TM_ARGMAX_STEP(dpp_x1)
-            TM_ARGMAX_STEP(dpp_x2)
-            TM_ARGMAX_STEP(dpp_hm)
-#undef TM_ARGMAX_STEP
-            sel = (int)rl_u32(bi, 0);
+            // a NaN at i >= 1 never wins, a NaN at 0 is never replaced, ties keep the lower index.  Compared as
+            // order-preserving integer keys (-0 folded into +0, as the float compare treats them as equal).
+            uint32_t qb = __float_as_uint(q);
+            qb = (qb == 0x80000000u) ? 0u : qb;
+            int key = (int)(qb ^ (((uint32_t)((int)qb >> 31)) >> 1));
+            if (q != q) key = (grp == 0) ? 0x7FFFFFFF : (int)0x80000000;
+            key = on ? key : (int)0x80000000;
+            const int kmax = group_max_i32(key);
+            sel = (__ffsll((long long)__ballot(key == kmax)) - 1) >> 3;
         }
-        idx = (int)rl_u32(c, sel);
-        {   // the selected child's record out of the prefetched block: piece k sits in lane 8*sel + k
-            const int src = sel * 8 + pf_k;
-            const uint32_t nx = shfl_u32(px, src), ny = shfl_u32(py, src), nz = shfl_u32(pz, src);
-            dx = (lane < 8) ? nx : 0u;
-            dy = (lane < 8) ? ny : 0u;
-            dz = (lane < 8) ? nz : 0u;
+        idx = (int)rl_u32(cur.x, sel * 8);
+        {   // piece j of the selected child's record sits in lane 8*sel + j of the prefetched block
+            const int src = sel * 32 + grp4;
+            cur.x = bperm_u32(src, pf.x);
+            cur.y = bperm_u32(src, pf.y);
+            cur.z = bperm_u32(src, pf.z);
+            cur.w = bperm_u32(src, pf.w);
         }
     }
+    hdr = rl_u32(cur.w, 56);
+    self_o = rl_u32(cur.y, 56);
+    const uint32_t self_sc = rl_u32(cur.z, 56);
     wave_sync();
     flush_trace(len);
     const long long tc_sel = __builtin_readcyclecounter();
     const int leaf = idx;
     const int leaf_end = (int)((hdr >> 24) & 1u);
-    int k_eval = 0;
-    int leaf_score = (int)P.game[(size_t)leaf * GAME_DW + 14];
-    if (overflow) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_TRACE); }
-    const int kind = S.kind;
+    int leaf_score = (int)P.game()[(size_t)leaf * GAME_DW + 14];
+    if (overflow) { if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_TRACE); }
     if (VANILLA && !leaf_end && !overflow) {
         // Vanilla.py:47-55: play a copy of the leaf to the end with uniformly random actions, value = final score
         uint32_t* ms = S.mt_state + (size_t)g * 625;
         for (int i = lane; i < 625; i += 64) { if (i < 624) M->mt[i] = ms[i]; else M->idx = ms[i]; }
-        if (lane < GAME_DW) L.slots[7][lane] = P.game[(size_t)leaf * GAME_DW + lane];
+        if (lane < GAME_DW) L.slots[7][lane] = P.game()[(size_t)leaf * GAME_DW + lane];
         wave_sync();
         if (lane == 0) {
             EngCfg cfg{S.app, S.scoring, S.randomizer};
@@ -744,49 +813,24 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         for (int i = lane; i < 625; i += 64) ms[i] = (i < 624) ? M->mt[i] : M->idx;
         wave_sync();
     }
-    if (!leaf_end && !overflow) {
-        uint32_t lh;
-        wave_expand(S, P, L, g, lane, leaf, lh);
-        if (VANILLA) {
-            k_eval = 0;
-            if (lane < S.eval_slots) P.eval_obs[lane] = 0;
-        } else if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT) {
-            k_eval = 1;
-            if (lane == 0) P.eval_obs[0] = (int)self_o;
-        } else {
-            // unique children of the freshly expanded leaf (ValueSimLP.py:55 / agent.cpp:424)
-            const int nu = (int)(lh & 7u);
-            k_eval = nu;
-            if (lane < 7) {
-                bool on = lane < nu;
-                P.leaf[lane] = on ? (int)L.misc[16 + lane] : 0;
-                P.leaf[7 + lane] = on ? (int)L.misc[24 + lane] : 0;
-                P.leaf[14 + lane] = on ? (int)L.misc[32 + lane] : 0;
-                P.eval_obs[lane] = on ? (int)L.misc[24 + lane] : 0;
-            }
-        }
-        if (lane == 0) P.gs[TM_GS_N_EXPAND] += 1;
-    } else {
-        if (lane < S.eval_slots) P.eval_obs[lane] = 0;
-    }
-    const long long tc_exp = __builtin_readcyclecounter();
+    // everything the expansion stage needs is in the control block: it is redone after a collection
     if (lane == 0) {
-        P.gs[TM_GS_CYC_SELECT] = (int)(tc_sel - tc_start);
-        P.gs[TM_GS_CYC_EXPAND] = (int)(tc_exp - tc_sel);
-        P.gs[TM_GS_TRACE_LEN] = len;
-        P.gs[TM_GS_PENDING] = 1;
-        P.gs[TM_GS_LEAF] = leaf;
-        P.gs[TM_GS_LEAF_END] = leaf_end | (overflow ? 1 : 0);
-        P.gs[TM_GS_K_EVAL] = k_eval;
-        P.gs[TM_GS_LEAF_SCORE] = leaf_score;
-        P.gs[TM_GS_TRACE_SUM] += len;
-        P.gs[TM_GS_N_EVAL] += k_eval;
-        if (nq_fallback) P.gs[TM_GS_N_NQ_FALLBACK] += nq_fallback;
+        int32_t* gs = P.gs();
+        gs[TM_GS_CYC_SELECT] = (int)(tc_sel - tc_start);
+        gs[TM_GS_TRACE_LEN] = len;
+        gs[TM_GS_LEAF] = leaf;
+        gs[TM_GS_LEAF_END] = leaf_end | (overflow ? 1 : 0);
+        gs[TM_GS_LEAF_SCORE] = leaf_score;
+        gs[TM_GS_TRACE_SUM] += len;
+        if (len > gs[TM_GS_MAX_TRACE]) gs[TM_GS_MAX_TRACE] = len;
+        if (nq_fallback) gs[TM_GS_N_NQ_FALLBACK] += nq_fallback;
+        gs[TM_GS_SIM_STARTED] += 1;
     }
     if (rng_pos != rng_pos0) {
         if (lane < 32) S.rng[(size_t)g * 32 + lane] = rs;
-        if (lane == 0) P.gs[TM_GS_RNG_POS] = rng_pos;
+        if (lane == 0) P.gs()[TM_GS_RNG_POS] = rng_pos;
     }
+    wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end | (overflow ? 1 : 0), self_o, self_sc);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -804,192 +848,251 @@ __device__ __forceinline__ bool bit_test(const uint8_t* bm, uint32_t i) {
     return (reinterpret_cast<const uint32_t*>(bm)[i >> 5] >> (i & 31)) & 1u;
 }
 
-__device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane) {
+// The collection is RESUMABLE: it runs in slices of about `budget` shader cycles (budget < 0: to completion), its
+// progress lives in the game's control block (TM_GS_GC_*), and a game that is collecting simply does not simulate in
+// that launch - the other 4095 games of the launch are not held up by one wavefront sweeping a 100 000-entry pool
+// (3 ms against a 0.1 ms launch).  The simulation that hit the empty pool is suspended in its expansion
+// (TM_GS_PENDING == 2) and redone when the collection is complete; the order of events inside the game is exactly
+// the reference's.  Returns true when the collection is complete.
+__device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, int lane, long long budget) {
     const long long gc_t0 = __builtin_readcyclecounter();
+    int32_t* gs = P.gs();
     const int N = S.max_nodes;
     const size_t bm_bytes = (((size_t)N + 7) / 8 + 15) & ~(size_t)15;
     uint8_t* nmark = S.gc_mark + (size_t)g * 2 * bm_bytes;
     uint8_t* omark = nmark + bm_bytes;
     int32_t* queue = S.gc_queue + (size_t)g * N;
     const uint32_t mask = (uint32_t)S.table_cap - 1u;
-    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
-    for (size_t i = lane; i < 2 * bm_bytes / 4; i += 64) reinterpret_cast<uint32_t*>(nmark)[i] = 0;
-    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
-    // breadth-first marking; index 0 is followed like any other child (core.h:41-45), so it stays occupied
-    int head = 0, tail = 1;
-    if (lane == 0) { queue[0] = P.gs[TM_GS_ROOT]; bit_test_set(nmark, (uint32_t)queue[0]); }
-    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
-    while (head < tail) {
-        int i = head + lane;
-        int cnt = 0;
-        uint32_t cs[7];
-        if (i < tail) {
-            const int node = queue[i];
-            // all loads of the round first, then all seven test-and-set atomics back to back (their latencies overlap),
-            // then the results: a round costs one atomic round trip instead of seven
-            const uint4 k0 = *reinterpret_cast<const uint4*>(P.kids + (size_t)node * TM_KIDS_DW);
-            const uint4 k1 = *reinterpret_cast<const uint4*>(P.kids + (size_t)node * TM_KIDS_DW + 4);
-            const uint32_t ob = P.rec[(size_t)node * TM_REC_DW + TM_REC_OBS];
-            const uint32_t ch[7] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z};
-            uint32_t old[7];
-#pragma unroll
-            for (int a = 0; a < 7; ++a)
-                old[a] = atomicOr(reinterpret_cast<uint32_t*>(nmark) + (ch[a] >> 5), 1u << (ch[a] & 31));
-            atomicOr(reinterpret_cast<uint32_t*>(omark) + (ob >> 5), 1u << (ob & 31));
-#pragma unroll
-            for (int a = 0; a < 7; ++a)
-                if (!((old[a] >> (ch[a] & 31)) & 1u)) cs[cnt++] = ch[a];
-        }
-        head = min(tail, head + 64);
-        // append this round's discoveries: exclusive scan of cnt over the wave
-        int incl = cnt;
-        for (int d = 1; d < 64; d <<= 1) {
-            int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        int total = __shfl(incl, 63, 64);
-        int off = tail + incl - cnt;
-        for (int j = 0; j < cnt; ++j) queue[off + j] = (int)cs[j];
-        tail += total;
-        // the queue is produced and consumed by this wave only: a workgroup-scope fence (wait for the stores, same-CU
-        // L1 is write-through) is enough, the device-scope one (L2 write-back + L1 invalidate) cost microseconds per batch
+    int phase = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_PHASE]);
+    int cursor = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_CURSOR]);
+    int tail = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_TAIL]);
+    int nfree = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_NFREE]);
+    int onfree = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_ONFREE]);
+    // the slice is over when its cycle budget is spent (uniform: s_memtime is a scalar read)
+    auto over = [&]() { return budget >= 0 && (long long)__builtin_readcyclecounter() - gc_t0 > budget; };
+    auto suspend = [&](int ph, int cur) {
         __threadfence_block();
-    }
-    // the root of an unexpanded tree still reaches node 0 through its zero child row
+        if (lane == 0) {
+            gs[TM_GS_GC_PHASE] = ph; gs[TM_GS_GC_CURSOR] = cur; gs[TM_GS_GC_TAIL] = tail;
+            gs[TM_GS_GC_NFREE] = nfree; gs[TM_GS_GC_ONFREE] = onfree;
+            gs[TM_GS_GC_CYC16] += (int)(((long long)__builtin_readcyclecounter() - gc_t0) >> 4);
+            gs[TM_GS_GC_SLICES] += 1;
+        }
+        __threadfence_block();
+        return false;
+    };
     __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
-    // both tables are rebuilt from what is kept: clear them first (nothing below reads them)
-    {   // 16-byte stores: two 8-byte entries each (table_cap is a power of two, the per-game tables are 16-byte aligned)
-        uint4* nt4 = reinterpret_cast<uint4*>(P.ntab);
-        uint4* ot4 = reinterpret_cast<uint4*>(P.otab);
+    if (phase == 1) {
+        for (size_t i = lane; i < 2 * bm_bytes / 4; i += 64) reinterpret_cast<uint32_t*>(nmark)[i] = 0;
+        __threadfence_block();
+        // breadth-first marking; index 0 is followed like any other child (core.h:41-45), so it stays occupied
+        if (lane == 0) { queue[0] = gs[TM_GS_ROOT]; bit_test_set(nmark, (uint32_t)queue[0]); }
+        __threadfence_block();
+        phase = 2; cursor = 0; tail = 1;
+    }
+    if (phase == 2) {
+        int head = cursor;
+        while (head < tail) {
+            int i = head + lane;
+            uint32_t ch[7] = {0, 0, 0, 0, 0, 0, 0};
+            uint32_t fresh = 0;     // bit a: child a was not marked before this round
+            if (i < tail) {
+                const int node = queue[i];
+                // all loads of the round first, then all seven test-and-set atomics back to back (their latencies overlap),
+                // then the results: a round costs one atomic round trip instead of seven
+                const uint4 k0 = *reinterpret_cast<const uint4*>(P.kids() + (size_t)node * TM_KIDS_DW);
+                const uint4 k1 = *reinterpret_cast<const uint4*>(P.kids() + (size_t)node * TM_KIDS_DW + 4);
+                const uint32_t ob = P.rec()[(size_t)node * TM_REC_DW + TM_REC_OBS];
+                ch[0] = k0.x; ch[1] = k0.y; ch[2] = k0.z; ch[3] = k0.w; ch[4] = k1.x; ch[5] = k1.y; ch[6] = k1.z;
+                uint32_t old[7];
+#pragma unroll
+                for (int a = 0; a < 7; ++a)
+                    old[a] = atomicOr(reinterpret_cast<uint32_t*>(nmark) + (ch[a] >> 5), 1u << (ch[a] & 31));
+                atomicOr(reinterpret_cast<uint32_t*>(omark) + (ob >> 5), 1u << (ob & 31));
+#pragma unroll
+                for (int a = 0; a < 7; ++a)
+                    if (!((old[a] >> (ch[a] & 31)) & 1u)) fresh |= 1u << a;
+            }
+            const int cnt = __popc(fresh);
+            head = min(tail, head + 64);
+            // append this round's discoveries: exclusive scan of cnt over the wave
+            int incl = cnt;
+            for (int d = 1; d < 64; d <<= 1) {
+                int t = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            int total = __shfl(incl, 63, 64);
+            int off = tail + incl - cnt;
+#pragma unroll
+            for (int a = 0; a < 7; ++a)
+                if ((fresh >> a) & 1u) queue[off + __popc(fresh & ((1u << a) - 1u))] = (int)ch[a];
+            tail += total;
+            // the queue is produced and consumed by this wave only: a workgroup-scope fence (wait for the stores, same-CU
+            // L1 is write-through) is enough, the device-scope one (L2 write-back + L1 invalidate) cost microseconds per batch
+            __threadfence_block();
+            if (head < tail && over()) return suspend(2, head);
+        }
+        // the root of an unexpanded tree still reaches node 0 through its zero child row
+        phase = 3; cursor = 0;
+    }
+    if (phase == 3) {
+        // both tables are rebuilt from what is kept: clear them first (nothing below reads them).  16-byte stores: two
+        // 8-byte entries each (table_cap is a power of two, the per-game tables are 16-byte aligned)
+        uint4* nt4 = reinterpret_cast<uint4*>(P.ntab());
+        uint4* ot4 = reinterpret_cast<uint4*>(P.otab());
         const uint4 z4 = make_uint4(0, 0, 0, 0);
-        for (size_t i = lane; i < (size_t)S.table_cap / 2; i += 64) { nt4[i] = z4; ot4[i] = z4; }
+        const int n4 = S.table_cap / 2;
+        while (cursor < n4) {
+            const int stop = min(n4, cursor + 64 * 64);     // 64 passes (128 KiB) between two looks at the clock
+            for (int i = cursor + lane; i < stop; i += 64) { nt4[i] = z4; ot4[i] = z4; }
+            cursor = stop;
+            if (cursor < n4 && over()) return suspend(3, cursor);
+        }
+        __threadfence_block();
+        phase = 4; cursor = 0; nfree = 0; onfree = 0;
     }
-    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
     // Sweeps over the pool: each lane takes one 32-bit word of a bitmap = 32 consecutive indices per pass (2048 per
     // wave pass), so a 100 000-entry pool is 49 passes instead of 1563 dependent ones.  Free lists come out ascending
     // (agents/agent.py:211-212,221-222): lane-major order is index order, positions from a wave prefix sum.  Freed
     // records are cleared by store-only streams (reset_arrays, agent.py:227-244); indices below the lowest index ever
     // allocated were never written and are skipped.
-    const int n_words = (N + 31) / 32;
-    const uint32_t* nw = reinterpret_cast<const uint32_t*>(nmark);
-    const uint32_t* ow = reinterpret_cast<const uint32_t*>(omark);
-    const int low_node = P.gs[TM_GS_LOW_NODE], low_obs = P.gs[TM_GS_LOW_OBS];
-    const bool harvest = S.online && S.replay_cap > 0;
-    int nfree = 0, onfree = 0;
-    int m = harvest ? S.replay_count[g] : 0;
-    auto wave_scan = [&](int v, int& total) {   // inclusive prefix sum over the wave
-        int incl = v;
-        for (int d = 1; d < 64; d <<= 1) {
-            int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        total = __shfl(incl, 63, 64);
-        return incl;
-    };
-    for (int wbase = 0; wbase < n_words; wbase += 64) {
-        const int wi = wbase + lane;
-        uint32_t valid = 0;
-        if (wi < n_words) { int rem = N - wi * 32; valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u); }
-        // ---- nodes ----
-        const uint32_t fr = (wi < n_words) ? (~nw[wi] & valid) : 0u;
-        int total;
-        int pos = nfree + wave_scan(__popc(fr), total) - __popc(fr);
-        // Freed records are not cleared here: new_node initialises a slot completely when it hands it out (the
-        // reference zeroes at GC, agents/agent.py:227-244; nothing reads a free slot in between).
-        for (uint32_t bits = fr; bits; bits &= bits - 1) P.fnode[pos++] = wi * 32 + (__ffs(bits) - 1);
-        nfree += total;
-        // ---- observations ----
-        const uint32_t ofr = (wi < n_words) ? (~ow[wi] & valid) : 0u;
-        int ototal;
-        int opos = onfree + wave_scan(__popc(ofr), ototal) - __popc(ofr);
-        uint32_t keepmask = 0;
-        if (harvest) {
-            // store_nodes (ValueSim.py:122-159): freed observations with enough visits that are not terminal
-            for (uint32_t bits = ofr; bits;) {
-                int ob[4];
-                uint4 st4[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    ob[u] = bits ? (__ffs(bits) - 1) : -1;
-                    bits &= bits ? bits - 1 : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int o = wi * 32 + (ob[u] < 0 ? 0 : ob[u]);
-                    st4[u] = (ob[u] >= 0 && o >= low_obs) ? *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4) : make_uint4(0, 0, 0, 0);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (ob[u] >= 0 && (int)st4[u].x >= S.min_visits_to_store && !(st4[u].w & 1u)) keepmask |= 1u << ob[u];
+    if (phase == 4) {
+        const int n_words = (N + 31) / 32;
+        const uint32_t* nw = reinterpret_cast<const uint32_t*>(nmark);
+        const uint32_t* ow = reinterpret_cast<const uint32_t*>(omark);
+        const int low_obs = gs[TM_GS_LOW_OBS];
+        const bool harvest = S.online && S.replay_cap > 0;
+        int m = harvest ? S.replay_count[g] : 0;
+        int dropped = 0;
+        auto wave_scan = [&](int v, int& total) {   // inclusive prefix sum over the wave
+            int incl = v;
+            for (int d = 1; d < 64; d <<= 1) {
+                int t = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += t;
             }
-            int ktotal;
-            int kpos = m + wave_scan(__popc(keepmask), ktotal) - __popc(keepmask);
-            for (uint32_t bits = keepmask; bits; bits &= bits - 1) {
+            total = __shfl(incl, 63, 64);
+            return incl;
+        };
+        for (int wbase = cursor; wbase < n_words; wbase += 64) {
+            const int wi = wbase + lane;
+            uint32_t valid = 0;
+            if (wi < n_words) { int rem = N - wi * 32; valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u); }
+            // ---- nodes ----
+            const uint32_t fr = (wi < n_words) ? (~nw[wi] & valid) : 0u;
+            int total;
+            int pos = nfree + wave_scan(__popc(fr), total) - __popc(fr);
+            // Freed records are not cleared here: new_node initialises a slot completely when it hands it out (the
+            // reference zeroes at GC, agents/agent.py:227-244; nothing reads a free slot in between).
+            for (uint32_t bits = fr; bits; bits &= bits - 1) P.fnode()[pos++] = wi * 32 + (__ffs(bits) - 1);
+            nfree += total;
+            // ---- observations ----
+            const uint32_t ofr = (wi < n_words) ? (~ow[wi] & valid) : 0u;
+            int ototal;
+            int opos = onfree + wave_scan(__popc(ofr), ototal) - __popc(ofr);
+            uint32_t keepmask = 0;
+            if (harvest) {
+                // store_nodes (ValueSim.py:122-159): freed observations with enough visits that are not terminal
+                for (uint32_t bits = ofr; bits;) {
+                    int ob[4];
+                    uint4 st4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        ob[u] = bits ? (__ffs(bits) - 1) : -1;
+                        bits &= bits ? bits - 1 : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int o = wi * 32 + (ob[u] < 0 ? 0 : ob[u]);
+                        st4[u] = (ob[u] >= 0 && o >= low_obs) ? *reinterpret_cast<const uint4*>(P.stat() + (size_t)o * 4) : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (ob[u] >= 0 && (int)st4[u].x >= S.min_visits_to_store && !(st4[u].x >> 31)) keepmask |= 1u << ob[u];
+                }
+                int ktotal;
+                int kpos = m + wave_scan(__popc(keepmask), ktotal) - __popc(keepmask);
+                for (uint32_t bits = keepmask; bits; bits &= bits - 1) {
+                    const int o = wi * 32 + (__ffs(bits) - 1);
+                    if (kpos < S.replay_cap) {
+                        const uint4 st = *reinterpret_cast<const uint4*>(P.stat() + (size_t)o * 4);
+                        const uint4* sk = reinterpret_cast<const uint4*>(P.okey() + (size_t)o * TM_OBS_DW);
+                        uint4* dk = reinterpret_cast<uint4*>(S.replay_obs + ((size_t)g * S.replay_cap + kpos) * TM_OBS_DW);
+                        dk[0] = sk[0]; dk[1] = sk[1]; dk[2] = sk[2];
+                        float* ds = S.replay_stat + ((size_t)g * S.replay_cap + kpos) * 4;
+                        ds[0] = __uint_as_float(st.y); ds[1] = __uint_as_float(st.z); ds[2] = (float)(int)st.x; ds[3] = 0.f;
+                    }
+                    kpos += 1;
+                }
+                if (m + ktotal > S.replay_cap) dropped += m + ktotal - S.replay_cap;   // never silently (the reference keeps all up to memory_size)
+                m = min(S.replay_cap, m + ktotal);
+            }
+            for (uint32_t bits = (wi < n_words) ? (ow[wi] & valid) : 0u; bits; bits &= bits - 1) {
+                const int o = wi * 32 + (__ffs(bits) - 1);     // kept observation: back into the (cleared) table
+                if (o == 0) continue;
+                uint32_t key[OBS_DW];
+                const uint4* src = reinterpret_cast<const uint4*>(P.okey() + (size_t)o * OBS_DW);
+                for (int t = 0; t < 3; ++t) { uint4 v = src[t]; key[4*t] = v.x; key[4*t+1] = v.y; key[4*t+2] = v.z; key[4*t+3] = v.w; }
+                const uint64_t h = hash_obs(key);
+                uint32_t sl = (uint32_t)h & mask;
+                const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)o;
+                while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.otab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
+            }
+            // Of a freed observation only the statistics are cleared (16 B): a visit count of 0 is what keeps a slot that
+            // stays free from being harvested again at the next GC.  Fully free words: one contiguous 512-byte store.
+            const bool ofull = (wi < n_words) && valid == 0xFFFFFFFFu && ofr == 0xFFFFFFFFu && (wi * 32 >= low_obs);
+            for (uint64_t fm = __ballot(ofull); fm; fm &= fm - 1) {
+                const int w0 = (wbase + (__ffsll((long long)fm) - 1)) * 32;
+                if (lane < 32) reinterpret_cast<uint4*>(P.stat() + (size_t)w0 * 4)[lane] = make_uint4(0, 0, 0, 0);
+            }
+            for (uint32_t bits = ofr; bits; bits &= bits - 1) {
                 const int o = wi * 32 + (__ffs(bits) - 1);
-                if (kpos < S.replay_cap) {
-                    const uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
-                    const uint4* sk = reinterpret_cast<const uint4*>(P.okey + (size_t)o * TM_OBS_DW);
-                    uint4* dk = reinterpret_cast<uint4*>(S.replay_obs + ((size_t)g * S.replay_cap + kpos) * TM_OBS_DW);
-                    dk[0] = sk[0]; dk[1] = sk[1]; dk[2] = sk[2];
-                    float* ds = S.replay_stat + ((size_t)g * S.replay_cap + kpos) * 4;
-                    ds[0] = __uint_as_float(st.y); ds[1] = __uint_as_float(st.z); ds[2] = (float)(int)st.x; ds[3] = 0.f;
-                }
-                kpos += 1;
+                P.fobs()[opos++] = o;
+                if (o >= low_obs && !ofull) *reinterpret_cast<uint4*>(P.stat() + (size_t)o * 4) = make_uint4(0, 0, 0, 0);
             }
-            m = min(S.replay_cap, m + ktotal);
+            onfree += ototal;
+            if (harvest && lane == 0) { S.replay_count[g] = m; if (dropped) { gs[TM_GS_N_DROPPED] += dropped; } }
+            dropped = 0;
+            if (wbase + 64 < n_words && over()) return suspend(4, wbase + 64);
         }
-        for (uint32_t bits = (wi < n_words) ? (ow[wi] & valid) : 0u; bits; bits &= bits - 1) {
-            const int o = wi * 32 + (__ffs(bits) - 1);     // kept observation: back into the (cleared) table
-            if (o == 0) continue;
-            uint32_t key[OBS_DW];
-            const uint4* src = reinterpret_cast<const uint4*>(P.okey + (size_t)o * OBS_DW);
-            for (int t = 0; t < 3; ++t) { uint4 v = src[t]; key[4*t] = v.x; key[4*t+1] = v.y; key[4*t+2] = v.z; key[4*t+3] = v.w; }
-            const uint64_t h = hash_obs(key);
-            uint32_t sl = (uint32_t)h & mask;
-            const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)o;
-            while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.otab[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
-        }
-        // Of a freed observation only the statistics are cleared (16 B): a visit count of 0 is what keeps a slot that
-        // stays free from being harvested again at the next GC.  Fully free words: one contiguous 512-byte store.
-        const bool ofull = (wi < n_words) && valid == 0xFFFFFFFFu && ofr == 0xFFFFFFFFu && (wi * 32 >= low_obs);
-        for (uint64_t fm = __ballot(ofull); fm; fm &= fm - 1) {
-            const int w0 = (wbase + (__ffsll((long long)fm) - 1)) * 32;
-            if (lane < 32) reinterpret_cast<uint4*>(P.stat + (size_t)w0 * 4)[lane] = make_uint4(0, 0, 0, 0);
-        }
-        for (uint32_t bits = ofr; bits; bits &= bits - 1) {
-            const int o = wi * 32 + (__ffs(bits) - 1);
-            P.fobs[opos++] = o;
-            if (o >= low_obs && !ofull) *reinterpret_cast<uint4*>(P.stat + (size_t)o * 4) = make_uint4(0, 0, 0, 0);
-        }
-        onfree += ototal;
+        __threadfence_block();
+        phase = 5; cursor = 0;
     }
-    if (harvest && lane == 0) S.replay_count[g] = m;
-    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
-    // re-insert the kept nodes (the BFS queue lists them)
-    // parallel reinsertion: lanes claim empty slots with a 64-bit compare-and-swap (no deletions happen
-    // concurrently, so linear probing stays consistent; placement order does not affect lookups)
-    for (int base = 0; base < tail; base += 64) {
-        int q = base + lane;
-        int i = (q < tail) ? queue[q] : 0;
-        if (i != 0) {
-            uint32_t key[GAME_DW];
-            const uint4* src = reinterpret_cast<const uint4*>(P.game + (size_t)i * GAME_DW);
-            for (int t = 0; t < 4; ++t) { uint4 v = src[t]; key[4*t] = v.x; key[4*t+1] = v.y; key[4*t+2] = v.z; key[4*t+3] = v.w; }
-            uint64_t h = hash_game(key);
-            uint32_t s = (uint32_t)h & mask;
-            unsigned long long ent = ((h >> 32) << 32) | (uint32_t)i;
-            while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.ntab[s]), 0ull, ent) != 0ull) s = (s + 1) & mask;
+    if (phase == 5) {
+        // re-insert the kept nodes (the BFS queue lists them): lanes claim empty slots with a 64-bit compare-and-swap (no
+        // deletions happen concurrently, so linear probing stays consistent; placement order does not affect lookups)
+        for (int base = cursor; base < tail; base += 64) {
+            int q = base + lane;
+            int i = (q < tail) ? queue[q] : 0;
+            if (i != 0) {
+                uint32_t key[GAME_DW];
+                const uint4* src = reinterpret_cast<const uint4*>(P.game() + (size_t)i * GAME_DW);
+                for (int t = 0; t < 4; ++t) { uint4 v = src[t]; key[4*t] = v.x; key[4*t+1] = v.y; key[4*t+2] = v.z; key[4*t+3] = v.w; }
+                uint64_t h = hash_game(key);
+                uint32_t sl = (uint32_t)h & mask;
+                unsigned long long ent = ((h >> 32) << 32) | (uint32_t)i;
+                while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.ntab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
+            }
+            if (base + 64 < tail && over()) return suspend(5, base + 64);
         }
     }
     if (lane == 0) {
-        P.gs[TM_GS_NFREE_NODE] = nfree;
-        P.gs[TM_GS_NFREE_OBS] = onfree;
-        P.gs[TM_GS_N_GC] += 1;
-        P.gs[TM_GS_CYC_TAIL] = (int)((__builtin_readcyclecounter() - gc_t0) >> 4);   // last GC, in units of 16 cycles
-        P.gs[TM_GS_CYC_TAIL + 1] = tail;                                                // reachable nodes at the last GC
+        gs[TM_GS_NFREE_NODE] = nfree;
+        gs[TM_GS_NFREE_OBS] = onfree;
+        gs[TM_GS_N_GC] += 1;
+        gs[TM_GS_CYC_TAIL] = gs[TM_GS_GC_CYC16] + (int)(((long long)__builtin_readcyclecounter() - gc_t0) >> 4);   // last GC, units of 16 cycles
+        gs[TM_GS_CYC_TAIL + 1] = tail;                                                // reachable nodes at the last GC
+        gs[TM_GS_GC_PHASE] = 0; gs[TM_GS_GC_CURSOR] = 0; gs[TM_GS_GC_CYC16] = 0;
+        gs[TM_GS_GC_SLICES] += 1;
     }
     __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
+    return true;
+}
+// to completion, now (update_root's exhausting pop: once per move at most, and almost never)
+__device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane) {
     (void)L;
+    if (lane == 0) P.gs()[TM_GS_GC_PHASE] = 1;
+    __threadfence_block();
+    gc_run(S, P, g, lane, -1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -998,25 +1101,58 @@ __device__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int l
 template <bool VANILLA>
 __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags) {
     __shared__ WaveLds lds[WPB];
-    __shared__ float nq_lds[NQ_LDS];
     extern __shared__ __attribute__((aligned(16))) MtLds mt_lds[];   // WPB entries, only in the VANILLA instantiation
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is uniform by construction: say so, and every per-game base pointer lives in scalar registers
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int g = blockIdx.x * WPB + w;
-    if (flags & TM_SIM_FRONT) {
-        for (int i = threadIdx.x; i < NQ_LDS; i += 64 * WPB) nq_lds[i] = (i < S.nq_size) ? S.nq_table[i] : 0.f;
-        __syncthreads();
-    }
     if (g >= S.n_games) return;
     GP P = game_ptrs(S, g);
     WaveLds& L = lds[w];
+    int32_t* gs = P.gs();
+    if (gs[TM_GS_GC_PHASE] != 0) {
+        // this game is collecting garbage: one slice per launch (S.gc_slice_cycles; 0 = to completion), no simulation
+        if (!gc_run(S, P, g, lane, S.gc_slice_cycles > 0 ? (long long)S.gc_slice_cycles : -1)) return;
+    }
+    const int pend = gs[TM_GS_PENDING];
+    if (pend == 2) {
+        // the simulation suspended in its expansion: redo the expansion of its leaf, post the evaluation requests
+        const int leaf = gs[TM_GS_LEAF];
+        const uint32_t self_o = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_OBS];
+        const uint32_t self_sc = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_SCORE];
+        wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc);
+        return;
+    }
     const long long t0 = __builtin_readcyclecounter();
-    if ((flags & TM_SIM_BACKUP) && P.gs[TM_GS_PENDING]) {
+    if ((flags & TM_SIM_BACKUP) && pend == 1) {
         wave_sim_back(S, P, L, lane);
         __threadfence_block();
     }
     const long long t1 = __builtin_readcyclecounter();
-    if (lane == 0) P.gs[TM_GS_CYC_BACK] = (int)(t1 - t0);
-    if (flags & TM_SIM_FRONT) wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, nq_lds, g, lane);
+    if (lane == 0) gs[TM_GS_CYC_BACK] = (int)(t1 - t0);
+    // the per-move quota (tm_move_begin): games that lost launches to a collection catch up in extra launches
+    if ((flags & TM_SIM_FRONT) && gs[TM_GS_SIM_STARTED] < gs[TM_GS_SIM_TARGET])
+        wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane);
+    else if (lane < S.eval_slots) P.eval_obs()[lane] = 0;      // nothing started: no request (the evaluator skips empty slots)
+}
+
+// per-move simulation quota (TreeAgent.play: self.mcts(self.root, self.sims), agents/agent.py:147-150)
+__global__ void k_move_begin(tm_store S, int sims) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= S.n_games) return;
+    int32_t* gs = S.gs + (size_t)g * TM_GS_DW;
+    gs[TM_GS_SIM_TARGET] = gs[TM_GS_SIM_STARTED] + sims;
+}
+// launches still needed before every game has finished its quota: max over games of (simulations not started yet
+// + one launch for the pending backup + one if a collection is in progress); atomicMax into *out (zeroed by the caller)
+__global__ void k_sims_remaining(tm_store S, int32_t* out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = 0;
+    if (g < S.n_games) {
+        const int32_t* gs = S.gs + (size_t)g * TM_GS_DW;
+        r = (gs[TM_GS_SIM_TARGET] - gs[TM_GS_SIM_STARTED]) + (gs[TM_GS_PENDING] != 0 ? 1 : 0) + (gs[TM_GS_GC_PHASE] != 0 ? 1 : 0);
+    }
+    for (int d = 32; d >= 1; d >>= 1) r = max(r, __shfl_xor(r, d, 64));
+    if ((threadIdx.x & 63) == 0 && r > 0) atomicMax(out, r);
 }
 
 // agent.update_root(game) (agents/agent.py:296-301)
@@ -1034,11 +1170,11 @@ __global__ __launch_bounds__(64 * WPB) void k_update_root(tm_store S) {
     if (idx < 0) {
         gc_wave(S, P, L, g, lane);   // reachable set of the OLD root, as in the reference
         wave_new_nodes(S, P, L, g, 1, lane, idx, o);
-        if (idx < 0) { if (lane == 0) atomicOr(&P.gs[TM_GS_ERR], TM_ERR_POOL); idx = 0; }
+        if (idx < 0) { if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_POOL); idx = 0; }
     }
     if (lane == 0) {
-        P.gs[TM_GS_ROOT] = idx;
-        if ((L.slots[0][11] >> 8) & 1u) P.gs[TM_GS_EPISODE] += 1;
+        P.gs()[TM_GS_ROOT] = idx;
+        if ((L.slots[0][11] >> 8) & 1u) P.gs()[TM_GS_EPISODE] += 1;
     }
 }
 
@@ -1047,22 +1183,22 @@ __global__ void k_root_stats(tm_store S, float* stats, int32_t* action) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= S.n_games) return;
     GP P = game_ptrs(S, g);
-    const int root = P.gs[TM_GS_ROOT];
-    float self = __uint_as_float(P.rec[(size_t)root * TM_REC_DW + TM_REC_SCORE]);
+    const int root = P.gs()[TM_GS_ROOT];
+    float self = __uint_as_float(P.rec()[(size_t)root * TM_REC_DW + TM_REC_SCORE]);
     float* out = stats + (size_t)g * 21;
     const bool cpp = (S.kind == TM_KIND_CPPAGENT_LP || S.kind == TM_KIND_CPPAGENT);
     int best = 0, first_nan = -1;
     float bestv = 0;
     for (int a = 0; a < 7; ++a) {
-        const uint32_t c = P.kids[(size_t)root * TM_KIDS_DW + a];    // child 0 = null node: record all zero
-        const uint32_t o = P.rec[(size_t)c * TM_REC_DW + TM_REC_OBS];
-        const float sc = __uint_as_float(P.rec[(size_t)c * TM_REC_DW + TM_REC_SCORE]);
-        uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)o * 4);
+        const uint32_t c = P.kids()[(size_t)root * TM_KIDS_DW + a];    // child 0 = null node: record all zero
+        const uint32_t o = P.rec()[(size_t)c * TM_REC_DW + TM_REC_OBS];
+        const float sc = __uint_as_float(P.rec()[(size_t)c * TM_REC_DW + TM_REC_SCORE]);
+        uint4 st = *reinterpret_cast<const uint4*>(P.stat() + (size_t)o * 4);
         float value = __uint_as_float(st.y);
         float v1;
         if (cpp) { float t = value + sc; v1 = t - self; }
         else { float diff = sc - self; v1 = value + diff; }
-        out[a] = (float)(int)st.x;
+        out[a] = (float)(int)(st.x & 0x7FFFFFFFu);
         out[7 + a] = v1;
         out[14 + a] = __uint_as_float(st.z);
         if (v1 != v1 && first_nan < 0) first_nan = a;
@@ -1076,18 +1212,18 @@ __global__ void k_pool_init(tm_store S) {
     int g = blockIdx.x;
     GP P = game_ptrs(S, g);
     const int N = S.max_nodes;
-    for (int i = threadIdx.x; i < N - 1; i += blockDim.x) { P.fnode[i] = i + 1; P.fobs[i] = i + 1; }
+    for (int i = threadIdx.x; i < N - 1; i += blockDim.x) { P.fnode()[i] = i + 1; P.fobs()[i] = i + 1; }
     if (threadIdx.x == 0) {
-        for (int i = 0; i < TM_GS_DW; ++i) P.gs[i] = 0;
-        P.gs[TM_GS_NFREE_NODE] = N - 1;
-        P.gs[TM_GS_NFREE_OBS] = N - 1;
-        P.gs[TM_GS_LOW_NODE] = N;
-        P.gs[TM_GS_LOW_OBS] = N;
+        for (int i = 0; i < TM_GS_DW; ++i) P.gs()[i] = 0;
+        P.gs()[TM_GS_NFREE_NODE] = N - 1;
+        P.gs()[TM_GS_NFREE_OBS] = N - 1;
+        P.gs()[TM_GS_LOW_NODE] = N;
+        P.gs()[TM_GS_LOW_OBS] = N;
         uint32_t r[32];
         int pos;
         srand_state(r, pos, 1u);   // the reference never calls srand(): glibc's default seed
         for (int i = 0; i < 32; ++i) S.rng[(size_t)g * 32 + i] = r[i];
-        P.gs[TM_GS_RNG_POS] = pos;
+        P.gs()[TM_GS_RNG_POS] = pos;
         if (S.replay_count) S.replay_count[g] = 0;
     }
 }
@@ -1100,28 +1236,32 @@ __global__ void k_pool_reset(tm_store S, const uint8_t* mask) {
     GP P = game_ptrs(S, g);
     const int N = S.max_nodes;
     const uint4 z = make_uint4(0, 0, 0, 0);
-    uint4* rec = reinterpret_cast<uint4*>(P.rec);
+    uint4* rec = reinterpret_cast<uint4*>(P.rec());
     for (size_t i = threadIdx.x; i < (size_t)N * TM_REC_DW / 4; i += blockDim.x) rec[i] = z;
-    uint4* kd = reinterpret_cast<uint4*>(P.kids);
+    uint4* kd = reinterpret_cast<uint4*>(P.kids());
     for (size_t i = threadIdx.x; i < (size_t)N * TM_KIDS_DW / 4; i += blockDim.x) kd[i] = z;
-    uint4* gm = reinterpret_cast<uint4*>(P.game);
+    uint4* gm = reinterpret_cast<uint4*>(P.game());
     for (size_t i = threadIdx.x; i < (size_t)N * GAME_DW / 4; i += blockDim.x) gm[i] = z;
-    uint4* stt = reinterpret_cast<uint4*>(P.stat);
+    uint4* stt = reinterpret_cast<uint4*>(P.stat());
     for (size_t i = threadIdx.x; i < (size_t)N; i += blockDim.x) stt[i] = z;
-    uint4* ok = reinterpret_cast<uint4*>(P.okey);
+    uint4* ok = reinterpret_cast<uint4*>(P.okey());
     for (size_t i = threadIdx.x; i < (size_t)N * OBS_DW / 4; i += blockDim.x) ok[i] = z;
-    for (size_t i = threadIdx.x; i < (size_t)S.table_cap; i += blockDim.x) { P.ntab[i] = 0; P.otab[i] = 0; }
-    for (int i = threadIdx.x; i < N - 1; i += blockDim.x) { P.fnode[i] = i + 1; P.fobs[i] = i + 1; }
+    for (size_t i = threadIdx.x; i < (size_t)S.table_cap; i += blockDim.x) { P.ntab()[i] = 0; P.otab()[i] = 0; }
+    for (int i = threadIdx.x; i < N - 1; i += blockDim.x) { P.fnode()[i] = i + 1; P.fobs()[i] = i + 1; }
     if (threadIdx.x == 0) {
-        P.gs[TM_GS_ROOT] = 0;
-        P.gs[TM_GS_NFREE_NODE] = N - 1;
-        P.gs[TM_GS_NFREE_OBS] = N - 1;
-        P.gs[TM_GS_LOW_NODE] = N;
-        P.gs[TM_GS_LOW_OBS] = N;
-        P.gs[TM_GS_TRACE_LEN] = 0;
-        P.gs[TM_GS_PENDING] = 0;
-        P.gs[TM_GS_ERR] &= ~TM_ERR_POOL;
-        P.gs[TM_GS_N_POOL_RESET] += 1;
+        P.gs()[TM_GS_ROOT] = 0;
+        P.gs()[TM_GS_NFREE_NODE] = N - 1;
+        P.gs()[TM_GS_NFREE_OBS] = N - 1;
+        P.gs()[TM_GS_LOW_NODE] = N;
+        P.gs()[TM_GS_LOW_OBS] = N;
+        P.gs()[TM_GS_TRACE_LEN] = 0;
+        P.gs()[TM_GS_PENDING] = 0;
+        P.gs()[TM_GS_GC_PHASE] = 0;
+        P.gs()[TM_GS_GC_RETRY] = 0;
+        P.gs()[TM_GS_GC_CYC16] = 0;
+        P.gs()[TM_GS_SIM_STARTED] = P.gs()[TM_GS_SIM_TARGET];
+        P.gs()[TM_GS_ERR] &= ~TM_ERR_POOL;
+        P.gs()[TM_GS_N_POOL_RESET] += 1;
     }
 }
 
@@ -1205,15 +1345,15 @@ __global__ void k_export_game(tm_store S, int g, int32_t* child, float* score, i
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S.max_nodes) return;
     GP P = game_ptrs(S, g);
-    const uint32_t* r = P.rec + (size_t)i * TM_REC_DW;
-    for (int a = 0; a < 7; ++a) child[(size_t)i * 7 + a] = (int)P.kids[(size_t)i * TM_KIDS_DW + a];
+    const uint32_t* r = P.rec() + (size_t)i * TM_REC_DW;
+    for (int a = 0; a < 7; ++a) child[(size_t)i * 7 + a] = (int)P.kids()[(size_t)i * TM_KIDS_DW + a];
     score[i] = __uint_as_float(r[TM_REC_SCORE]);
     n_to_o[i] = (int)r[TM_REC_OBS];
-    uint4 st = *reinterpret_cast<const uint4*>(P.stat + (size_t)i * 4);
-    visit[i] = (int)st.x;
+    uint4 st = *reinterpret_cast<const uint4*>(P.stat() + (size_t)i * 4);
+    visit[i] = (int)(st.x & 0x7FFFFFFFu);
     value[i] = __uint_as_float(st.y);
     variance[i] = __uint_as_float(st.z);
-    end_obs[i] = (uint8_t)(st.w & 1u);
+    end_obs[i] = (uint8_t)(st.x >> 31);
 }
 
 }  // namespace tmcts
@@ -1277,6 +1417,16 @@ int tm_sim_step(const tm_store* s, int flags, void* stream) {
         hipLaunchKernelGGL(k_sim_step<false>, grid, block, 0, (hipStream_t)stream, *s, flags);
     return TM_LAUNCH_CHECK();
 }
+int tm_move_begin(const tm_store* s, int sims, void* stream) {
+    hipLaunchKernelGGL(k_move_begin, dim3((s->n_games + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s, sims);
+    return TM_LAUNCH_CHECK();
+}
+int tm_sims_remaining(const tm_store* s, int32_t* out, void* stream) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(int32_t), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_sims_remaining, dim3((s->n_games + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s, out);
+    return TM_LAUNCH_CHECK();
+}
 int tm_eval_render(const tm_store* s, int8_t* out, void* stream) {
     hipLaunchKernelGGL(k_eval_render, dim3(s->n_games * s->eval_slots), dim3(256), 0, (hipStream_t)stream, *s, out);
     return TM_LAUNCH_CHECK();
@@ -1298,7 +1448,7 @@ int tm_export_game(const tm_store* s, int game, int32_t* child, float* score, in
 extern "C" int tm_store_layout(int* out, int n) {
     int v[] = {(int)sizeof(tm_store), (int)offsetof(tm_store, gamma), (int)offsetof(tm_store, node_rec),
                (int)offsetof(tm_store, nq_table), (int)offsetof(tm_store, replay_count), (int)offsetof(tm_store, mt_state),
-               (int)offsetof(tm_store, node_child)};
+               (int)offsetof(tm_store, node_child), (int)offsetof(tm_store, gc_slice_cycles)};
     int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < m; ++i) out[i] = v[i];
     return m;

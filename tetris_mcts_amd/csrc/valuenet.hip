@@ -76,10 +76,11 @@ __global__ void k_fc1_relu(const float* __restrict__ a3, int stride, const float
 }
 
 __global__ void k_fc_out(const float* __restrict__ h, int hstride, const float* __restrict__ P, float* __restrict__ v,
-                         float* __restrict__ var, int n) {
+                         float* __restrict__ var, int n, const int32_t* __restrict__ eval_obs) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * 2) return;
     int s = t >> 1, j = t & 1;
+    if (eval_obs && eval_obs[s] == 0) return;   // unused evaluation slot: its outputs are never read
     float acc = P[OFF_FOB + j];
     const float* x = h + (size_t)s * hstride;
     const float* wr = P + OFF_FOW + j * HID;
@@ -394,10 +395,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int FC_KC = TM_FC_KC, FC_PITCH = FC_KC + 4;
 __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
-                                                float* __restrict__ hout, int hstride) {
+                                                float* __restrict__ hout, int hstride,
+                                                const int32_t* __restrict__ eval_obs) {
     __shared__ float bt[2][32 * FC_PITCH];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, l15 = lane & 15;
     const int s0 = blockIdx.x * 32;
+    if (eval_obs) {
+        // a tile of 32 request slots none of which carries a request (catch-up launches, finished games): nothing to do
+        const bool mine = threadIdx.x < 32 && s0 + (int)threadIdx.x < n && eval_obs[s0 + threadIdx.x] != 0;
+        if (!__syncthreads_or(mine)) return;
+    }
     const int ht = blockIdx.y * 8 + w;   // 16-row hidden tile 0..15
     const float4* W = reinterpret_cast<const float4*>(prep + PREP_W1) + (size_t)ht * 112 * 64 + lane;
     f32x4 acc0, acc1;
@@ -523,7 +530,8 @@ int tm_valuenet_forward_plain(const float* P, const int8_t* states, int n, float
                        (const int8_t*)nullptr, P + OFF_C3W, P + OFF_C3B, a1 + A1 + A2, SS, n);
     hipLaunchKernelGGL(k_fc1_relu, dim3((n * HID + T - 1) / T), dim3(T), 0, stream, a1 + A1 + A2, SS, P + OFF_F1W,
                        P + OFF_F1B, a1 + A1 + A2 + A3, SS, n);
-    hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + T - 1) / T), dim3(T), 0, stream, a1 + A1 + A2 + A3, SS, P, v, var, n);
+    hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + T - 1) / T), dim3(T), 0, stream, a1 + A1 + A2 + A3, SS, P, v, var, n,
+                       (const int32_t*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -545,8 +553,8 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, eval_obs,
                        eval_slots, max_nodes, n, scratch, SS);
     hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(512), 0, stream, P, prepared, scratch, SS, n,
-                       scratch + A3, SS);
-    hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, v, var, n);
+                       scratch + A3, SS, eval_obs);
+    hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, v, var, n, eval_obs);
     return (int)hipGetLastError();
 }
 

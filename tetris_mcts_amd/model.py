@@ -159,6 +159,17 @@ class Model_VV:
         return v_out, var_out
 
     @torch.no_grad()
+    def hip_buffers(self, n_states):
+        """(params, prepared operand streams, scratch for n_states) as ctypes pointers for the C ABI (search.hip)."""
+        if self._scratch is None or self._scratch.shape[0] < n_states or self._scratch.shape[1] < 2048:
+            self._scratch = torch.empty(n_states, 2048, dtype=torch.float32, device=self.device)
+        P = self.flat_params()
+        if self._prepared is None:
+            self._prepared = torch.empty(477184, dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib().tm_valuenet_prepare(_p(P), _p(self._prepared), _stream()), "tm_valuenet_prepare")
+        return _p(P), _p(self._prepared), _p(self._scratch)
+
+    @torch.no_grad()
     def inference_requests(self, store):
         """Evaluate a TreeStore's pending leaf requests in place (fused render + forward, HIP back end only)."""
         import ctypes as C

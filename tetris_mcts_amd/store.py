@@ -13,8 +13,9 @@ from . import _lib
 SIM_BACKUP, SIM_FRONT = 1, 2
 KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA = 0, 1, 2, 3, 4
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
-          RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18,
-          CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24)
+          RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18, MAX_TRACE=19, N_DROPPED=25,
+          CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_SLICES=38,
+          SIM_TARGET=40, SIM_STARTED=41)
 
 _nq_cache = {}
 
@@ -43,7 +44,7 @@ class TreeStore:
 
     def __init__(self, n_games, max_nodes=100000, kind=KIND_VALUESIM, env_args=((20, 10), 1, 0, 0), gamma=0.999,
                  low=1, eval_slots=None, max_trace=1024, nq_size=1 << 20, online=False, min_visits_to_store=10,
-                 replay_cap=0, device="cuda"):
+                 replay_cap=0, gc_slice_cycles=150000, device="cuda"):
         if not torch.cuda.is_available():
             raise RuntimeError("tetris_mcts_amd needs a ROCm GPU (gfx950); there is no CPU path")
         shape, app, scoring, randomizer = env_args[0], env_args[1], env_args[2], env_args[3]
@@ -62,9 +63,9 @@ class TreeStore:
         z = lambda *shape, dtype=torch.int32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         bm = ((N + 7) // 8 + 15) & ~15
         self.t = dict(
-            node_rec=z(G, N, 24), node_child=z(G, N, 8), node_game=z(G, N, 16), obs_stat=z(G, N, 4), obs_key=z(G, N, 12),
+            node_rec=z(G, N, 32), node_child=z(G, N, 8), node_game=z(G, N, 16), obs_stat=z(G, N, 4), obs_key=z(G, N, 12),
             node_tab=z(G, cap, dtype=torch.int64), obs_tab=z(G, cap, dtype=torch.int64),
-            free_node=z(G, N), free_obs=z(G, N), gs=z(G, 32), rng=z(G, 32), env_game=z(G, 16), env_line_stats=z(G, 4),
+            free_node=z(G, N), free_obs=z(G, N), gs=z(G, 64), rng=z(G, 32), env_game=z(G, 16), env_line_stats=z(G, 4),
             trace=z(G, max_trace, 4), leaf=z(G, 32), eval_obs=z(G * eval_slots),
             eval_v=z(G * eval_slots, dtype=torch.float32), eval_var=z(G * eval_slots, dtype=torch.float32),
             gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N),
@@ -77,14 +78,22 @@ class TreeStore:
         s.n_games, s.max_nodes, s.table_cap, s.max_trace, s.eval_slots, s.nq_size = G, N, cap, max_trace, eval_slots, nq_size
         s.app, s.scoring, s.randomizer = int(app), int(scoring), int(randomizer)
         s.low, s.kind, s.min_visits_to_store, s.online, s.replay_cap = int(low), int(kind), int(min_visits_to_store), int(bool(online)), int(replay_cap)
+        s.gc_slice_cycles = int(gc_slice_cycles)
         s.gamma = float(gamma)
-        for name, _ in _lib.TmStore._fields_[15:]:
+        for name, _ in _lib.TmStore._fields_[16:]:
             setattr(s, name, self.t[name].data_ptr())
         self.s = s
         self.stats_buf = torch.zeros(G, 3, 7, dtype=torch.float32, device=dev)
         self.action_buf = torch.zeros(G, dtype=torch.int32, device=dev)
         self.eval_states = torch.zeros(G * eval_slots, 200, dtype=torch.int8, device=dev)
+        self._rem = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._search = {}
         _lib.check(self.L.tm_pool_init(C.byref(s), _stream()), "tm_pool_init")
+
+    def __del__(self):
+        for h in getattr(self, "_search", {}).values():
+            self.L.tm_search_destroy(h)
+        self._search = {}
 
     def set_python_random_states(self, states):
         """states: one `random.getstate()` / `random.Random(seed).getstate()` per game (Vanilla's rollout RNG)."""
@@ -102,6 +111,41 @@ class TreeStore:
 
     def update_root(self):
         _lib.check(self.L.tm_update_root(C.byref(self.s), _stream()), "tm_update_root")
+
+    def move_begin(self, sims):
+        """Give every game a quota of `sims` more simulations (TreeAgent.play: mcts(root, sims), agents/agent.py:147-150)."""
+        _lib.check(self.L.tm_move_begin(C.byref(self.s), int(sims), _stream()), "tm_move_begin")
+
+    def sims_remaining(self):
+        """Launches still needed before every game has used its quota (host sync): > 0 only when a game spent launches
+        collecting garbage instead of simulating."""
+        _lib.check(self.L.tm_sims_remaining(C.byref(self.s), _p(self._rem), _stream()), "tm_sims_remaining")
+        return int(self._rem.item())
+
+    def search(self, sims, model=None, n_sub=1, ev_every=0):
+        """One move's search through the native launch loop (search.hip): `sims` simulations of every game, the leaf
+        evaluator = the HIP value net of `model` (None: no evaluator, the Vanilla kind).  Returns when complete."""
+        key = (int(n_sub), int(ev_every))
+        h = self._search.get(key)
+        if h is None:
+            h = C.c_void_p()
+            _lib.check(self.L.tm_search_create(C.byref(h), C.byref(self.s), key[0], key[1]), "tm_search_create")
+            self._search[key] = h
+        if model is None:
+            P = prep = scr = C.c_void_p(0)
+        else:
+            P, prep, scr = model.hip_buffers(self.n_games * self.eval_slots)
+        _lib.check(self.L.tm_search_run(h, int(sims), P, prep, scr, _stream()), "tm_search_run")
+
+    def search_stats(self, n_sub=1, ev_every=0, reset=True):
+        """dict of the native loop's counters and HIP-event timings (tm_search_stats)."""
+        h = self._search.get((int(n_sub), int(ev_every)))
+        if h is None:
+            return None
+        out = (C.c_double * 7)()
+        self.L.tm_search_stats(h, out, 7, int(bool(reset)))
+        keys = ("runs", "tree_launches", "catchup_launches", "timed", "tree_ms_sum", "nn_ms_sum", "n_sub")
+        return dict(zip(keys, list(out)))
 
     def sim_step(self, flags):
         _lib.check(self.L.tm_sim_step(C.byref(self.s), int(flags), _stream()), "tm_sim_step")
