@@ -4,10 +4,13 @@
 Metric: MCTS node-expansions/sec at 4096 concurrent games x 500 simulations/move (BASELINE configs[1]:
 ValueSim UCT with the value-net leaf evaluator), one process per GPU, games sharded (weak scaling).
 A "step" is one move of every game: 500 simulations (select / expand / evaluate / backup) for each of the
-rank's games, then get_action, game.play and update_root.  State is resident in HBM before the timed region.
+rank's games through the native launch loop (search.hip), then get_action, game.play and update_root.
+State is resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    ... --online     harvest (state, TD-target) tuples at every garbage collection and all-gather them over the ranks
+                     after every move inside the timed region (BASELINE configs[3]: RCCL used for exactly that)
 """
 import argparse
 import json
@@ -23,23 +26,27 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STATE = 3803136            # conv1 82,944 + conv2 1,769,472 + conv3 1,032,192 + fc1 917,504 + fc_out 1,024
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
+PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
-def pmc_traffic(kernels, fetch_scale=1.0):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json; counters can
-    not be read from inside this process, and the guide asks for separate passes).  FETCH_SIZE + WRITE_SIZE are
-    KiB per dispatch; fetch_scale = 2 for kernels whose reads are wide coalesced streams (gfx950 under-report)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def pmc_traffic(kernels, workload_key, fetch_scale=1.0):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS workload (counters can not be read from
+    inside this process, and the guide asks for separate passes): only used when the file was recorded with the same
+    command line (its "workload_key"), otherwise the traffic is reported as null.  FETCH_SIZE + WRITE_SIZE are KiB per
+    dispatch; fetch_scale = 2 for kernels whose reads are wide coalesced streams (gfx950 under-report)."""
+    path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        k = json.load(f)["kernels"]
+        doc = json.load(f)
+    if doc.get("workload_key") != workload_key:
+        return None
     tot = 0.0
     for name in kernels:
-        e = k.get(name)
-        if not e:
+        e = doc["kernels"].get(name)
+        if not e or "FETCH_SIZE_KB_mean" not in e or "WRITE_SIZE_KB_mean" not in e:
             return None
-        tot += 1024.0 * (fetch_scale * e["FETCH_SIZE_KB_last50_mean"] + e["WRITE_SIZE_KB_last50_mean"])
+        tot += 1024.0 * (fetch_scale * e["FETCH_SIZE_KB_mean"] + e["WRITE_SIZE_KB_mean"])
     return tot
 
 
@@ -59,11 +66,14 @@ def main():
     ap.add_argument("--agent", default="ValueSim", choices=["ValueSim", "ValueSimLP"])
     ap.add_argument("--max-nodes", type=int, default=100000)
     ap.add_argument("--backend", default="hip", choices=["hip", "torch"])
-    ap.add_argument("--graph", action="store_true", help="replay the simulation body as a hipGraph (no per-kernel events)")
-    ap.add_argument("--split", type=int, default=1, help="run the rank's games as this many independent sub-batches on "
-                    "separate HIP streams, so one sub-batch's tree kernel overlaps another's value-net kernels")
+    ap.add_argument("--split", type=int, default=int(os.environ.get("TM_BENCH_SPLIT", "1")),
+                    help="sub-batches of the rank's games on separate HIP streams (one sub-batch's tree kernel runs "
+                    "under another's value-net kernels)")
+    ap.add_argument("--gc-slice-cycles", type=int, default=150000)
+    ap.add_argument("--online", action="store_true", help="harvest training tuples at GC and all-gather them every move")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the N-process CPU baseline (0: all host cores, at most 128)")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,85 +94,70 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    from tetris_mcts_amd import agents, store as st
+    from tetris_mcts_amd import agents, store as st, dist as tdist
     from tetris_mcts_amd.model import Model_VV
     from tetris_mcts_amd.pyTetris import Tetris
 
-    G, sims = args.games, args.sims
-    NS = args.split
-    assert G % NS == 0
-    Gs = G // NS
+    G, sims, NS = args.games, args.sims, args.split
+    EV_EVERY = int(os.environ.get("TM_BENCH_EVENT_EVERY", "16"))
     env_args = ((20, 10), 1, 0, 0)
     model = Model_VV(backend=args.backend, seed=0)  # model_vv.Net() under torch.manual_seed(0) (random init)
     base_seed = 20260925 + rank * G
-    streams = [torch.cuda.Stream() for _ in range(NS)] if NS > 1 else [torch.cuda.current_stream()]
-    games, agts, models = [], [], []
-    for k in range(NS):
-        with torch.cuda.stream(streams[k]):
-            mk = model if k == 0 else Model_VV(backend=args.backend, seed=0)   # own scratch per stream, same weights
-            game = Tetris(*env_args, seed=base_seed + k * Gs, n_games=Gs)
-            agent = getattr(agents, args.agent)(sims=sims, env=Tetris, env_args=env_args, n_games=Gs,
-                                                max_nodes=args.max_nodes, model=mk, online=False, use_graph=args.graph)
-            agent.update_root(game)
-        games.append(game); agts.append(agent); models.append(mk)
+    game = Tetris(*env_args, seed=base_seed, n_games=G)
+    okw = dict(online=True, min_visits_to_store=10, replay_cap=16384) if args.online else dict(online=False)
+    agent = getattr(agents, args.agent)(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=args.max_nodes,
+                                        model=model, n_sub=NS, ev_every=EV_EVERY, gc_slice_cycles=args.gc_slice_cycles,
+                                        **okw)
+    agent.update_root(game)
     torch.cuda.synchronize()
-    stores = [a.store for a in agts]
-    dev = stores[0].device
-    K = stores[0].eval_slots
-
-    ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(sims)] for _ in range(NS)] if not args.graph else None
-    # HIP events bracket every EV_EVERY-th simulation of the timed region (two event records per launch cost ~7 us of
-    # stream time per simulation, 3 % of a step, when placed around all of them)
-    EV_EVERY = int(os.environ.get("TM_BENCH_EVENT_EVERY", "16"))
-    t_tree = t_nn = 0.0
-    n_tree = n_nn = 0
+    S = agent.store
+    dev = S.device
+    K = S.eval_slots
+    NS = agent.n_sub
     episodes, lines = 0, 0
+    gather = dict(ms=0.0, tuples=0, bytes=0, calls=0, checksum_ok=True)
 
     def one_step(timed):
-        nonlocal t_tree, t_nn, n_tree, n_nn, episodes, lines
-        if args.graph:
-            for k in range(NS):
-                with torch.cuda.stream(streams[k]):
-                    agts[k].mcts(sims)
-        else:
-            for i in range(sims):
-                for k in range(NS):
-                    with torch.cuda.stream(streams[k]):
-                        e = ev[k][i] if i % EV_EVERY == 0 else None
-                        if e: e[0].record()
-                        stores[k].sim_step(st.SIM_BACKUP | st.SIM_FRONT)
-                        if e: e[1].record()
-                        agts[k].evaluate_requests()
-                        if e: e[2].record()
-            for k in range(NS):
-                with torch.cuda.stream(streams[k]):
-                    stores[k].sim_step(st.SIM_BACKUP)
-        for k in range(NS):
-            with torch.cuda.stream(streams[k]):
-                _, action = stores[k].root_stats()
-                games[k].play(action)
-                agts[k].update_root(games[k])   # reads game.end: one small host sync per move, as the reference's loop has
-                ended = np.atleast_1d(games[k].end)
-                if ended.any():
-                    episodes += int(ended.sum())
-                    lines += int(np.atleast_1d(games[k].line_clears)[ended].sum())
-                    games[k].reset("ended")
-                    agts[k].update_root(games[k])
-        if timed and not args.graph:
+        nonlocal episodes, lines
+        agent.mcts(sims)
+        _, action = S.root_stats()
+        game.play(action)
+        agent.update_root(game)   # reads game.end: one small host sync per move, as the reference's loop has
+        ended = np.atleast_1d(game.end)
+        if ended.any():
+            if timed:
+                episodes += int(ended.sum())
+                lines += int(np.atleast_1d(game.line_clears)[ended].sum())
+            game.reset("ended")
+            agent.update_root(game)
+        if args.online:
+            # the one exchange step of the job: this rank's freshly harvested tuples -> every rank (RCCL all-gather)
+            t0 = time.perf_counter()
+            keys, stats = S.replay()
+            S.t["replay_count"].zero_()
+            local_sum = keys.to(torch.int64).sum() + stats.view(torch.int32).to(torch.int64).sum()
+            n_local = keys.shape[0]
+            ka, sa = tdist.all_gather_tuples(keys.view(torch.int32), stats)
+            tot = torch.stack([local_sum, torch.tensor(n_local, device=dev, dtype=torch.int64)])
+            if world > 1:
+                dist.all_reduce(tot)
             torch.cuda.synchronize()
-            for k in range(NS):
-                for e in ev[k][::EV_EVERY]:
-                    t_tree += e[0].elapsed_time(e[1])
-                    t_nn += e[1].elapsed_time(e[2])
-            n_tree += len(ev[0][::EV_EVERY]) * NS
-            n_nn += len(ev[0][::EV_EVERY]) * NS
+            if timed:
+                gather["ms"] += 1e3 * (time.perf_counter() - t0)
+                gather["tuples"] += int(ka.shape[0])
+                gather["bytes"] += int(ka.shape[0]) * 64
+                gather["calls"] += 1
+                # the gathered multiset is the union of the ranks' harvests: same count, same word sum
+                got = ka.to(torch.int64).sum() + sa.view(torch.int32).to(torch.int64).sum()
+                gather["checksum_ok"] &= bool(int(tot[1].item()) == int(ka.shape[0]) and int(tot[0].item()) == int(got.item()))
 
     def counters():
-        return {k: sum(S.counter(k) for S in stores) for k in ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL")}
+        return {k: S.counter(k) for k in ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL", "N_GC", "GC_SLICES", "N_DROPPED")}
 
     for _ in range(args.warmup):
         one_step(False)
     torch.cuda.synchronize()
+    S.search_stats(NS, EV_EVERY, reset=True)
     if world > 1:
         dist.barrier()
     c0 = counters()
@@ -175,22 +170,28 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     c1 = counters()
-    err = sum(int((S.errors() != 0).sum().item()) for S in stores)
+    ss = S.search_stats(NS, EV_EVERY, reset=False) or {}
+    err = int((S.errors() != 0).sum().item())
+    max_trace = int(S.t["gs"][:, st.GS["MAX_TRACE"]].max().item())
     d = {k: c1[k] - c0[k] for k in c0}
-    tot = torch.tensor([elapsed, d["N_EXPAND"], d["N_SIMS"], d["TRACE_SUM"], d["N_EVAL"], episodes, lines, err],
+    tot = torch.tensor([elapsed, d["N_EXPAND"], d["N_SIMS"], d["TRACE_SUM"], d["N_EVAL"], episodes, lines, err,
+                        d["N_GC"], d["GC_SLICES"], d["N_DROPPED"], ss.get("catchup_launches", 0.0)],
                        dtype=torch.float64, device=dev)
     if world > 1:
         tmax = tot[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         tot[0] = tmax[0]
-    elapsed, n_exp, n_sims, tr_sum, n_eval, episodes, lines, err = [float(x) for x in tot.cpu()]
+    elapsed, n_exp, n_sims, tr_sum, n_eval, episodes, lines, err, n_gc, gc_slices, dropped, catchup = [float(x) for x in tot.cpu()]
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
     mean_len = tr_sum / max(n_sims, 1.0)
+    cfg_idx = 1 if args.agent == "ValueSim" else 2
+    workload_key = "%s G=%d sims=%d pool=%d warmup=%d steps=%d split=%d" % (args.agent, G, sims, args.max_nodes,
+                                                                           args.warmup, args.steps, NS)
     out = {
         "metric": "mcts_node_expansions_per_sec",
         "value": n_exp / elapsed,
@@ -202,42 +203,59 @@ def main():
         "config": {
             "workload": "%d games/GPU x %d sims/move, %s UCT with value-net leaf evaluation (BASELINE configs[%d]); "
                         "Tetris 20x10 app=1 guideline scoring 7-bag; node pool %d/game; Net() random init manual_seed(0)"
-                        % (G, sims, args.agent, 1 if args.agent == "ValueSim" else 2, args.max_nodes),
+                        % (G, sims, args.agent, cfg_idx, args.max_nodes),
+            "workload_key": workload_key,
             "games_per_gpu": G, "sims_per_move": sims, "agent": args.agent, "max_nodes": args.max_nodes,
-            "valuenet_backend": args.backend, "graph": bool(args.graph), "streams": NS,
+            "valuenet_backend": args.backend, "sub_batches": NS, "online": bool(args.online),
+            "gc_slice_cycles": args.gc_slice_cycles,
         },
         "sims_per_sec": n_sims / elapsed,
         "child_steps_per_sec": 7.0 * n_exp / elapsed,
         "evaluated_states_per_sec": n_eval / elapsed,
         "mean_trace_len": mean_len,
+        "max_trace_len": max_trace,
         "episodes_finished": int(episodes),
         "lines_cleared_per_episode": (lines / episodes) if episodes else None,
+        "lines_note": None if episodes else "no episode ends inside the timed window (random-init network, moves %d-%d "
+                      "of every game); the learning curve (lines cleared per episode vs training round) is "
+                      "scripts/selfplay_online.py -> profiles/*_online_learning.jsonl" % (args.warmup + 1, args.warmup + args.steps),
         "error_games": int(err),
-        "store_gib_per_gpu": sum(S.nbytes() for S in stores) / 2**30,
-        "last_sim_phase_kcycles": {k: float(np.mean([S.t["gs"][:, st.GS[k]].float().mean().item() for S in stores])) / 1e3
-                                   for k in ("CYC_BACK", "CYC_SELECT", "CYC_EXPAND", "TRACE_LEN")},
+        "gc": {"collections": int(n_gc), "slices": int(gc_slices), "catchup_launches": int(catchup),
+               "dropped_tuples": int(dropped)},
+        "store_gib_per_gpu": S.nbytes() / 2**30,
+        "last_sim_phase_kcycles": {k: float(S.t["gs"][:, st.GS[k]].float().mean().item()) / 1e3
+                                   for k in ("CYC_BACK", "CYC_SELECT", "CYC_EXPAND")},
     }
-    if not args.graph and n_nn:
-        nn_ms, tree_ms = t_nn / n_nn, t_tree / n_tree
-        evals_per_launch = n_eval / (args.steps * sims * world * NS)
+    if args.online:
+        out["exchange"] = {"what": "all-gather of the (packed observation, value, variance, visit) tuples harvested at GC, "
+                                   "once per move (tetris_mcts_amd/dist.py all_gather_tuples, backend nccl = RCCL)",
+                           "calls": gather["calls"], "tuples": gather["tuples"], "bytes": gather["bytes"],
+                           "ms_total": gather["ms"], "multiset_check": gather["checksum_ok"]}
+    if ss.get("timed"):
+        nn_ms, tree_ms = ss["nn_ms_sum"] / ss["timed"], ss["tree_ms_sum"] / ss["timed"]
+        Gs = G / NS
+        evals_per_launch = n_eval / max(n_sims, 1.0) * Gs
         flops = FLOP_PER_STATE * evals_per_launch
         a_tf = flops / (nn_ms * 1e-3) / 1e12
         bps = bytes_per_sim(mean_len, 1 if args.agent == "ValueSim" else n_eval / max(n_exp, 1.0))
         a_gbs = bps * Gs / (tree_ms * 1e-3) / 1e9
-        nn_roof = {"kernel": "value net forward (tm_valuenet_forward + eval render), per launch of %d states" % (Gs * K),
+        note = ("bytes/launch from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line); null when "
+                "that file was recorded for another workload" % PMC_FILE)
+        nn_roof = {"kernel": "value net forward (k_vn_conv + k_vn_fc1 + k_fc_out), per launch of %d request slots" % int(Gs * K),
                    "bound": "mfma", "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                    "frac": a_tf / PEAK_F32_MATRIX_TFLOPS,
-                   "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1", "tmcts_vn::k_fc_out"], 2.0)
+                   "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1", "tmcts_vn::k_fc_out"], workload_key, 2.0)
                    if args.backend == "hip" else None,
-                   "traffic_note": "bytes/launch, FETCH_SIZE x2 (wide streams) + WRITE_SIZE from profiles/r01_pmc_traffic.json",
-                   "avg_launch_ms": nn_ms, "launches_timed": int(n_nn), "events_every": EV_EVERY}
-        tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % Gs, "bound": "hbm",
+                   "traffic_note": note + "; FETCH_SIZE x2 (wide streams)",
+                   "avg_launch_ms": nn_ms, "launches_timed": int(ss["timed"]), "events_every": EV_EVERY}
+        tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % int(Gs), "bound": "hbm",
                      "achieved": a_gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBPS,
-                     "traffic": pmc_traffic(["tmcts::k_sim_step<false>"]),
-                     "traffic_note": "bytes/launch of 4096 games at mean trace length ~20 (move 1), FETCH_SIZE + WRITE_SIZE "
-                                     "from profiles/r01_pmc_traffic.json (narrow scattered accesses: no gfx950 correction)",
-                     "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps, "launches_timed": int(n_tree),
-                     "events_every": EV_EVERY}
+                     "traffic": pmc_traffic(["tmcts::k_sim_step<false>"], workload_key),
+                     "traffic_note": note + " (narrow scattered accesses: no gfx950 correction)",
+                     "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps, "launches_timed": int(ss["timed"]),
+                     "events_every": EV_EVERY,
+                     "timing_note": "HIP events on the sub-batch's own stream around every %d-th simulation; with %d "
+                                    "sub-batches the kernels of other streams share the device during the interval" % (EV_EVERY, NS)}
         out["roofline"] = nn_roof if nn_ms >= tree_ms else tree_roof
         out["roofline_other"] = tree_roof if nn_ms >= tree_ms else nn_roof
     if world == 1 and not args.no_cpu_baseline:
@@ -247,43 +265,50 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, model):
-    """CPU baseline on this box's host cores, 1 thread, bounded sample of the same workload (1 game, same sims/move,
-    same network weights).  Preferred: kind "reference" = the reference's own all-C++ MCTSAgent (agents/cppmodule/
-    agent.cpp compiled in place into oracle/_ref/, the ValueSimC path) with a single-thread torch CPU evaluator.
-    Fallback / secondary: kind "port" = the oracle's C restatement incl. its fma-chain value net."""
-    import torch
-    from oracle import binding as B
-    out = None
-    lp = args.agent != "ValueSim"
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (reported only): the reference's own compiled agent on this box's host cores
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_worker(kind, sims, max_nodes, lp, seconds, seed, state_dict, q):
+    """One process = one game on one core, as the reference deploys them (cycle.sh:69-71)."""
     try:
-        agent_mod = B.load_ref_native("agent")
-        if agent_mod is not None:
+        import numpy as np
+        import torch
+        torch.set_num_threads(1)
+        from oracle import binding as B
+        if kind == "reference":
+            agent_mod = B.load_ref_native("agent")
+            if agent_mod is None:
+                q.put(None)
+                return
             sys.path.insert(0, B.BUILD)
             from pyTetris import Tetris as OTetris
             from tetris_mcts_amd.model import Net
-            torch.set_num_threads(1)
             net = Net().eval()
-            net.load_state_dict({k: v.detach().cpu() for k, v in model.model.state_dict().items()})
-            n_calls = [0, 0]
+            net.load_state_dict(state_dict)
+            n_eval = [0]
 
             def ev(obs):
                 x = torch.from_numpy(np.asarray(obs).astype(np.float32))
                 with torch.no_grad():
                     y = net(x.reshape(-1, 1, 20, 10))
-                n_calls[0] += 1
-                n_calls[1] += y.shape[0]
+                n_eval[0] += y.shape[0]
                 if lp:
                     return [y[:, 0].tolist(), y[:, 1].tolist()]
                 return [float(y[0, 0]), float(y[0, 1])]
             import ctypes
             ctypes.CDLL("libc.so.6").srand(1)
-            ag = agent_mod.MCTSAgent(args.sims, args.max_nodes, True, 0.999, False, ev, 0, lp)
-            g = OTetris((20, 10), 1, 0, 0, 20260925)
+            g = OTetris((20, 10), 1, 0, 0, seed)
+            # expand() executions = evaluator calls: MCTSAgent evaluates exactly the non-terminal leaves it then expands
+            n_exp = [0]
+
+            def ev_count(obs):
+                n_exp[0] += 1
+                return ev(obs)
+            ag = agent_mod.MCTSAgent(sims, max_nodes, True, 0.999, False, ev_count, 0, lp)
             ag.update_root(g)
             t0 = time.perf_counter()
             moves = 0
-            while time.perf_counter() - t0 < args.cpu_seconds:
+            while time.perf_counter() - t0 < seconds:
                 g.play(int(ag.play()))
                 ag.update_root(g)
                 moves += 1
@@ -291,37 +316,88 @@ def cpu_baseline(args, model):
                     g.reset()
                     ag.update_root(g)
             dt = time.perf_counter() - t0
-            out = {"value": n_calls[0] / dt, "unit": "node-expansions/s", "cores": 1, "kind": "reference",
-                   "sample": "1 game x %d moves x %d sims/move, the reference's own MCTSAgent (agent.cpp compiled in place, "
-                             "LP=%s) + torch CPU Net, 1 thread, %.1f s" % (moves, args.sims, lp, dt),
-                   "sims_per_sec": moves * args.sims / dt, "evaluated_states_per_sec": n_calls[1] / dt,
-                   "host_cpus": os.cpu_count()}
-    except Exception as e:  # the reference build is optional on the GPU box
-        out = None
-        sys.stderr.write("reference CPU baseline unavailable (%s); using the oracle port\n" % (e,))
-    kind = 0 if args.agent == "ValueSim" else 1
-    params = model.flat_params().cpu().numpy()
-    g = B.Game(seed=20260925)
-    a = B.Agent(kind, max_nodes=args.max_nodes, evaluator="valuenet", params=params)
-    a.update_root(g)
-    t0 = time.perf_counter()
-    moves = 0
-    budget = args.cpu_seconds if out is None else min(args.cpu_seconds, 5.0)
-    while time.perf_counter() - t0 < budget:
-        g.play(a.play(args.sims))
-        a.update_root(g)
-        moves += 1
-        if g.end:
-            g.reset()
+            q.put(dict(expansions=n_exp[0], sims=moves * sims, evals=n_eval[0], moves=moves, seconds=dt))
+        else:
+            params = torch.cat([state_dict[k].reshape(-1).float() for k in state_dict]).numpy()
+            g = B.Game(seed=seed)
+            a = B.Agent(1 if lp else 0, max_nodes=max_nodes, evaluator="valuenet", params=params)
             a.update_root(g)
-    dt = time.perf_counter() - t0
-    port = {"value": a.n_expand / dt, "unit": "node-expansions/s", "cores": 1, "kind": "port",
-            "sample": "1 game x %d moves x %d sims/move, oracle C restatement of %s incl. fp32 value net, %.1f s" %
-                      (moves, args.sims, args.agent, dt),
-            "sims_per_sec": a.n_sims / dt, "host_cpus": os.cpu_count()}
-    if out is None:
-        return port
-    out["port"] = port
+            t0 = time.perf_counter()
+            moves = 0
+            while time.perf_counter() - t0 < seconds:
+                g.play(a.play(sims))
+                a.update_root(g)
+                moves += 1
+                if g.end:
+                    g.reset()
+                    a.update_root(g)
+            dt = time.perf_counter() - t0
+            q.put(dict(expansions=a.n_expand, sims=a.n_sims, evals=a.n_expand, moves=moves, seconds=dt))
+    except Exception as e:  # reported, never fatal for the benchmark line
+        q.put(dict(error=repr(e)))
+
+
+def _cpu_run(kind, nproc, args, state_dict, seconds):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    lp = args.agent != "ValueSim"
+    procs = [ctx.Process(target=_cpu_worker, args=(kind, args.sims, args.max_nodes, lp, seconds, 20260925 + i, state_dict, q))
+             for i in range(nproc)]
+    t0 = time.perf_counter()
+    for p in procs:
+        p.start()
+    res = []
+    for _ in procs:
+        try:
+            res.append(q.get(timeout=seconds * 6 + 240))
+        except Exception:
+            res.append(None)
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+    wall = time.perf_counter() - t0
+    ok = [r for r in res if r and "error" not in r]
+    errs = [r["error"] for r in res if r and "error" in r]
+    if not ok:
+        return None, errs
+    rate = sum(r["expansions"] / r["seconds"] for r in ok)
+    return dict(value=rate, procs_ok=len(ok), expansions=sum(r["expansions"] for r in ok), sims=sum(r["sims"] for r in ok),
+                sims_per_sec=sum(r["sims"] / r["seconds"] for r in ok), moves=sum(r["moves"] for r in ok),
+                seconds_each=seconds, wall=wall), errs
+
+
+def cpu_baseline(args, model):
+    """the reference timed on this box's host cores, reported only.  kind "reference" = the reference's
+    own all-C++ MCTSAgent (agents/cppmodule/agent.cpp compiled in place into oracle/_ref/ - the ValueSimC / best-case
+    path) with a single-thread torch CPU `Net` as its evaluator, (a) 1 process on 1 core and (b) one process per host
+    core (independent games, the reference's own deployment, cycle.sh:69-71).  `value` = expand() executions per second
+    (= evaluator calls of MCTSAgent: it evaluates exactly the leaves it expands).  The reference's *Python* ValueSim
+    needs the reference sources at run time (/root/reference is not on the GPU box), so it is timed only where the
+    sources are (DESIGN.md section 5 lists that number).  Fallback kind "port": the oracle's C restatement."""
+    sd = {k: v.detach().cpu() for k, v in model.model.state_dict().items()}
+    ncpu = os.cpu_count() or 1
+    nproc = args.cpu_procs or min(ncpu, 128)
+    sample = "1 game per process x %d sims/move from a fresh game (seed 20260925+i), pool %d, same network weights, %.0f s per process"
+    kind = "reference"
+    one, errs = _cpu_run(kind, 1, args, sd, args.cpu_seconds)
+    if one is None:
+        kind = "port"
+        one, errs = _cpu_run(kind, 1, args, sd, args.cpu_seconds)
+    if one is None:
+        return {"value": None, "unit": "node-expansions/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % errs[:1]}
+    many, errs2 = _cpu_run(kind, nproc, args, sd, args.cpu_seconds) if nproc > 1 else (None, [])
+    out = {"value": (many or one)["value"], "unit": "node-expansions/s", "cores": (many["procs_ok"] if many else 1), "kind": kind,
+           "sample": (sample % (args.sims, args.max_nodes, args.cpu_seconds)) +
+                     ("; the reference's compiled MCTSAgent (agent.cpp, LP=%s) + torch CPU Net, 1 thread per process" % (args.agent != "ValueSim")
+                      if kind == "reference" else "; oracle C restatement incl. its fp32 value net"),
+           "host_cpus": ncpu,
+           "one_core": {"value": one["value"], "sims_per_sec": one["sims_per_sec"], "moves": one["moves"]},
+           "all_cores": None if many is None else {"value": many["value"], "procs": many["procs_ok"], "sims_per_sec": many["sims_per_sec"],
+                                                   "per_core": many["value"] / max(many["procs_ok"], 1), "wall_s": many["wall"]}}
+    if errs or errs2:
+        out["worker_errors"] = (errs + errs2)[:3]
     return out
 
 

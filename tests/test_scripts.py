@@ -40,16 +40,17 @@ def test_pmc_traffic_summary_and_bench_reader(tmp_path, monkeypatch):
         _write(str(tmp_path / counter / "p_counter_collection.csv"), hdr, rows)
     oj, oc = tmp_path / "t.json", tmp_path / "t.csv"
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic.py"), str(oj), str(oc),
-                           str(tmp_path / "FETCH_SIZE"), str(tmp_path / "WRITE_SIZE")])
+                           str(tmp_path / "FETCH_SIZE"), str(tmp_path / "WRITE_SIZE"), "--workload-key", "K1"])
     k = json.load(open(oj))["kernels"]
     assert list(k) == ["tmcts::k_sim_step<false>"]
     assert k["tmcts::k_sim_step<false>"]["FETCH_SIZE_KB_mean"] == 20.0 and k["tmcts::k_sim_step<false>"]["launches"] == 2
-    # bench.py reads the same structure: bytes = 1024 * (fetch_scale * FETCH + WRITE) of the last-50 means
+    # bench.py reads the same structure, and only for the workload the passes were recorded on
     sys.path.insert(0, ROOT)
     import bench
     os.makedirs(tmp_path / "profiles")
-    os.replace(oj, tmp_path / "profiles" / "r01_pmc_traffic.json")
+    os.replace(oj, tmp_path / bench.PMC_FILE)
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    assert bench.pmc_traffic(["tmcts::k_sim_step<false>"]) == 1024.0 * (20.0 + 6.0)
-    assert bench.pmc_traffic(["tmcts::k_sim_step<false>"], 2.0) == 1024.0 * (40.0 + 6.0)
-    assert bench.pmc_traffic(["tmcts_vn::k_vn_conv"]) is None
+    assert bench.pmc_traffic(["tmcts::k_sim_step<false>"], "K1") == 1024.0 * (20.0 + 6.0)
+    assert bench.pmc_traffic(["tmcts::k_sim_step<false>"], "K1", 2.0) == 1024.0 * (40.0 + 6.0)
+    assert bench.pmc_traffic(["tmcts::k_sim_step<false>"], "another workload") is None
+    assert bench.pmc_traffic(["tmcts_vn::k_vn_conv"], "K1") is None
