@@ -224,7 +224,7 @@ def main():
                "dropped_tuples": int(dropped)},
         "store_gib_per_gpu": S.nbytes() / 2**30,
         "last_sim_phase_kcycles": {k: float(S.t["gs"][:, st.GS[k]].float().mean().item()) / 1e3
-                                   for k in ("CYC_BACK", "CYC_SELECT", "CYC_EXPAND")},
+                                   for k in ("CYC_BACK", "CYC_SELECT", "CYC_EXPAND", "CYC_WALK_MEM", "TRACE_LEN")},
     }
     if args.online:
         out["exchange"] = {"what": "all-gather of the (packed observation, value, variance, visit) tuples harvested at GC, "

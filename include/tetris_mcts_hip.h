@@ -58,7 +58,8 @@ enum {
     TM_GS_GC_RETRY,      /* the suspended expansion has already been through a collection */
     /* per-move simulation quota: tm_move_begin adds `sims` to the target; a launch starts a simulation for a game only
        while started < target, so games that lost launches to a collection catch up in extra launches (tm_sims_remaining) */
-    TM_GS_SIM_TARGET = 40, TM_GS_SIM_STARTED
+    TM_GS_SIM_TARGET = 40, TM_GS_SIM_STARTED,
+    TM_GS_CYC_WALK_MEM   /* profiling builds (-DTM_PROF_WALK): cycles of the last walk spent waiting for its loads */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */

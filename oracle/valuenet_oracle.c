@@ -71,7 +71,7 @@ static void conv3x3_relu(const float *in, int cin, int h, int w, const float *wt
 void orc_valuenet_forward(const float *P, const int8_t *states, int k, float *v, float *var) {
     const float *c1w = P, *c1b = c1w + 288, *c2w = c1b + 32, *c2b = c2w + 9216, *c3w = c2b + 32, *c3b = c3w + 9216,
                 *f1w = c3b + 32, *f1b = f1w + 458752, *fow = f1b + 256, *fob = fow + 512, *ub = fob + 2, *lb = ub + 2;
-    static float x0[200], a1[32 * 18 * 8], a2[32 * 16 * 6], a3[1792], h[256];
+    float x0[200], a1[32 * 18 * 8], a2[32 * 16 * 6], a3[1792], h[256];   /* on the stack: agents run in parallel threads in the tests */
     for (int s = 0; s < k; ++s) {
         for (int i = 0; i < 200; ++i) x0[i] = (float)states[200 * s + i];
         conv3x3_relu(x0, 1, 20, 10, c1w, c1b, a1);

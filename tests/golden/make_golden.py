@@ -432,8 +432,106 @@ def gen_agents_env():
         json.dump(out, f)
 
 
+def _legacy_torch_overloads():
+    """model/yogi.py and model/model_vv.py call `add(number, tensor)`, `add_(number, tensor)`, `addcmul_(number, t, t)` and
+    `addcdiv_(number, t, t)`, signatures PyTorch removed after 1.x.  Re-add them (number first = `alpha` / `value`) so the
+    reference's training code runs unmodified."""
+    import numbers
+    import torch
+    T = torch.Tensor
+    if getattr(T, "_tm_legacy", False):
+        return
+    orig = {n: getattr(T, n) for n in ("add", "add_", "addcmul_", "addcdiv_")}
+
+    def _num(x):
+        return isinstance(x, numbers.Number)
+
+    def add(self, *a, **k):
+        return orig["add"](self, a[1], alpha=a[0]) if len(a) == 2 and _num(a[0]) else orig["add"](self, *a, **k)
+
+    def add_(self, *a, **k):
+        return orig["add_"](self, a[1], alpha=a[0]) if len(a) == 2 and _num(a[0]) else orig["add_"](self, *a, **k)
+
+    def addcmul_(self, *a, **k):
+        return orig["addcmul_"](self, a[1], a[2], value=a[0]) if len(a) == 3 and _num(a[0]) else orig["addcmul_"](self, *a, **k)
+
+    def addcdiv_(self, *a, **k):
+        return orig["addcdiv_"](self, a[1], a[2], value=a[0]) if len(a) == 3 and _num(a[0]) else orig["addcdiv_"](self, *a, **k)
+    T.add, T.add_, T.addcmul_, T.addcdiv_, T._tm_legacy = add, add_, addcmul_, addcdiv_, True
+
+
+def gen_training():
+    """ref_training.npz: the reference's own optimiser, loss and training step on fixed tensors (CPU, 1 thread).
+      * model/yogi.py:39-90 `Yogi.step`: 10 steps on a [6,5] parameter, fp64 and fp32, lr 1e-3 eps 1e-3 wd 1e-3
+        (the settings of model_vv.py:132) -> the parameter after every step;
+      * model/model_vv.py:94-101 `GaussianLL.forward` on 64 samples;
+      * model/model_vv.py:136-150 `Model_VV._loss` + model/model.py:97-116 `Model.train` (zero_grad, loss, backward, step)
+        on the reference's own Net under manual_seed(0): loss values, gradient norms and all 478342 parameters
+        after 4 steps (weighted)."""
+    ref_shims.install()
+    _legacy_torch_overloads()
+    import torch
+    torch.set_num_threads(1)
+    from model.yogi import Yogi
+    from model.model_vv import GaussianLL, Model_VV
+    rng = np.random.default_rng(11)
+    out = {}
+    p0 = rng.standard_normal((6, 5))
+    grads = rng.standard_normal((10, 6, 5)) * np.array([1.0, 0.1, 3.0, 1e-3, 1.0, 10.0])[None, :, None]
+    out["yogi_p0"], out["yogi_grads"] = p0, grads
+    for dt, name in ((torch.float64, "f64"), (torch.float32, "f32")):
+        p = torch.nn.Parameter(torch.tensor(p0, dtype=dt))
+        opt = Yogi([p], lr=1e-3, eps=1e-3, weight_decay=1e-3)
+        traj = []
+        for g in grads:
+            p.grad = torch.tensor(g, dtype=dt)
+            opt.step()
+            traj.append(p.detach().numpy().copy())
+        out["yogi_traj_" + name] = np.stack(traj)
+    vp = (rng.random((64, 1)) * 50 + 0.1).astype(np.float32)
+    mp = (rng.standard_normal((64, 1)) * 30).astype(np.float32)
+    var = (rng.random((64, 1)) * 40 + 0.1).astype(np.float32)
+    mean = (rng.standard_normal((64, 1)) * 30).astype(np.float32)
+    out["ll_in"] = np.stack([vp, mp, var, mean])
+    out["ll_out"] = GaussianLL()(torch.from_numpy(vp.copy()), torch.from_numpy(mp.copy()), torch.from_numpy(var.copy()),
+                                 torch.from_numpy(mean.copy())).numpy()
+    torch.manual_seed(0)
+    m = Model_VV(use_cuda=False)
+    m.training(True)
+    n = 48
+    states = np.zeros((n, 1, 20, 10), np.float32)
+    for i in range(n):
+        h = int(rng.integers(0, 14))
+        states[i, 0, 20 - h:, :] = (rng.random((h, 10)) < 0.7)
+        states[i, 0, 1:3, 4:6] = -1
+    values = (rng.random((n, 1)) * 60).astype(np.float32)
+    variances = (rng.random((n, 1)) * 200).astype(np.float32)
+    variances[:5] = 0.01                                   # below the clip (model_vv.py:141: clamp at 0.1)
+    weights = rng.integers(10, 400, (n, 1)).astype(np.float32)
+    weights = weights / weights.mean()
+    out["tr_states"], out["tr_values"], out["tr_variances"], out["tr_weights"] = states, values, variances, weights
+    order = ["head.conv1.weight", "head.conv1.bias", "head.conv2.weight", "head.conv2.bias", "head.conv3.weight",
+             "head.conv3.bias", "head.fc1.weight", "head.fc1.bias", "head.fc_out.weight", "head.fc_out.bias",
+             "out_ubound", "out_lbound"]
+    flat = lambda: np.concatenate([m.model.state_dict()[k].detach().numpy().ravel() for k in order]).astype(np.float32)  # noqa: E731
+    out["tr_params0"] = flat()
+    losses, gnorms = [], []
+    for it in range(4):
+        r = m.train([states.copy(), values.copy(), variances.copy(), weights.copy()], weighted=True)
+        losses.append(r["loss"])
+        gnorms.append(r["grad_norm"])
+    out["tr_losses"], out["tr_gnorms"], out["tr_params4"] = np.asarray(losses, np.float64), np.asarray(gnorms, np.float64), flat()
+    val = m.compute_loss([states.copy(), values.copy(), variances.copy(), weights.copy()], weighted=True, chunksize=20)
+    out["tr_val"] = np.asarray([val["loss"], val["loss_std"]], np.float64)
+    # optimiser state layout of a reference checkpoint (model/model.py:152-160): 12 parameters in one group
+    sd = m.optimizer.state_dict()
+    out["opt_group_params"] = np.asarray(sd["param_groups"][0]["params"], np.int64)
+    np.savez_compressed(os.path.join(OUT, "ref_training.npz"), **out)
+    print("ref_training.npz: losses", losses, "grad norms", gnorms, "val", val)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -451,6 +549,8 @@ if __name__ == "__main__":
         gen_online_py()
     if "agents_env" in which:
         gen_agents_env()
+    if "training" in which:
+        gen_training()
     if "agents" in which:
         if params is None:
             params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]

@@ -733,6 +733,9 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     typedef const float __attribute__((address_space(4))) * const_f32_ptr;
     const const_f32_ptr nqt = (const_f32_ptr)(uintptr_t)S.nq_table;
     const int nq_size = S.nq_size, max_trace = S.max_trace;
+#ifdef TM_PROF_WALK
+    long long prof_mem = 0;
+#endif
     for (;;) {
         if (len >= max_trace) { overflow = true; break; }
         if (len - flushed == TRACE_LDS) { wave_sync(); flush_trace(len); wave_sync(); }
@@ -741,9 +744,16 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         const bool on = cur.x != 0u;
         if (__ballot(on) == 0ull) break;          // no children: a leaf
         // the loads of this level
+#ifdef TM_PROF_WALK
+        const long long tpa = __builtin_readcyclecounter();
+#endif
         const uint4 st = buf_ld16(stat_rs, cur.y * 16u);
         const uint4 pf = buf_ld16(rec_rs, cur.x * (TM_REC_DW * 4u) + pc16);
         const int visit = (int)(st.x & 0x7FFFFFFFu);
+#ifdef TM_PROF_WALK
+        asm volatile("" :: "v"(visit), "v"(pf.x));     // both loads have landed
+        prof_mem += __builtin_readcyclecounter() - tpa;
+#endif
         const uint64_t lowmask = __ballot(on && visit < low);
         int sel;
         if (lowmask) {
@@ -825,6 +835,9 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         if (len > gs[TM_GS_MAX_TRACE]) gs[TM_GS_MAX_TRACE] = len;
         if (nq_fallback) gs[TM_GS_N_NQ_FALLBACK] += nq_fallback;
         gs[TM_GS_SIM_STARTED] += 1;
+#ifdef TM_PROF_WALK
+        gs[TM_GS_CYC_WALK_MEM] = (int)prof_mem;
+#endif
     }
     if (rng_pos != rng_pos0) {
         if (lane < 32) S.rng[(size_t)g * 32 + lane] = rs;

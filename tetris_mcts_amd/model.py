@@ -64,8 +64,9 @@ class Model_VV:
     def _optimizer(self):
         if getattr(self, "optimizer", None) is None:
             from .train import Yogi
-            params = [p for p in self.model.parameters() if p.requires_grad]
-            self.optimizer = Yogi(params, lr=1e-3, eps=1e-3, weight_decay=1e-3)
+            # all 12 parameters in one group, out_ubound / out_lbound included, as model_vv.py:132 does
+            # (Yogi(self.model.parameters(), ...)): a checkpoint's optimizer_state_dict then loads on either side
+            self.optimizer = Yogi(self.model.parameters(), lr=1e-3, eps=1e-3, weight_decay=1e-3)
         return self.optimizer
 
     def train_data(self, data, **kwargs):
@@ -99,8 +100,10 @@ class Model_VV:
             if ck.get("optimizer_state_dict"):
                 try:
                     self._optimizer().load_state_dict(ck["optimizer_state_dict"])
-                except (ValueError, KeyError):
-                    pass   # a checkpoint written by a different optimiser layout: keep fresh optimiser state
+                except (ValueError, KeyError) as e:
+                    from sys import stderr
+                    print("WARNING: optimizer state of %s not loaded (%s): the optimiser restarts with fresh moments"
+                          % (filename, e), file=stderr, flush=True)
         else:
             print("Checkpoint not found, using default model", flush=True)
         self._flat = None
@@ -110,8 +113,9 @@ class Model_VV:
         if verbose:
             print("Saving model...", flush=True)
         os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
-        opt = self.optimizer.state_dict() if getattr(self, "optimizer", None) is not None else {}
-        torch.save({"model_state_dict": self.model.state_dict(), "optimizer_state_dict": opt}, filename)
+        # the reference's Model.load indexes optimizer_state_dict['param_groups'] (model.py:166-170): always write a real one
+        torch.save({"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self._optimizer().state_dict()},
+                   filename)
 
     def set_flat_params(self, flat):
         """flat: 478342 floats in PARAM_ORDER (tests/golden/ref_valuenet.npz 'params')."""

@@ -46,14 +46,16 @@ class Yogi(Optimizer):
                     st["exp_avg_sq"] = g * g
                 st["step"] += 1
                 t = st["step"]
+                # the reference's own sequence of tensor primitives (model/yogi.py:69-88), so parameter trajectories are
+                # bit-identical to it (tests/golden/ref_training.npz)
                 if group["weight_decay"] != 0:
-                    g = g + group["weight_decay"] * p
+                    g = g.add(p, alpha=group["weight_decay"])
                 m, v = st["exp_avg"], st["exp_avg_sq"]
                 m.mul_(b1).add_(g, alpha=1 - b1)
-                g2 = g * g
-                v.sub_((1 - b2) * torch.sign(v - g2) * g2)
-                denom = v.sqrt() / math.sqrt(1 - b2 ** t) + group["eps"]
-                p.sub_((group["lr"] / (1 - b1 ** t)) * m / denom)
+                g2 = g.mul(g)
+                v.addcmul_(torch.sign(v - g2), g2, value=-(1 - b2))
+                denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(group["eps"])
+                p.addcdiv_(m, denom, value=-(group["lr"] / (1 - b1 ** t)))
         return loss
 
 
@@ -70,7 +72,8 @@ def batch_loss(net, batch, weighted, variance_clip=variance_bound):
     per = gaussian_kl(var, v, variance, value)
     if weighted:
         per = weight * per
-    return per.mean(), per.std(unbiased=False)
+    std, mean = torch.std_mean(per, unbiased=False)      # model_vv.py:146-149 (one fused reduction: same bits as the reference)
+    return mean, std
 
 
 @torch.no_grad()
@@ -99,13 +102,18 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
     save() / load() persist and restore the best weights (the reference goes through its checkpoint file).
 
     With torch.distributed initialised and more than one rank (every rank holding the same data and the same weights, as
-    after dist.all_gather_tuples), `data_parallel` splits each batch: a rank draws batch_size / world samples of its
-    own, the flattened gradients (1.9 MB) are averaged with one all-reduce per iteration, and every rank takes the same
-    optimizer step - the replicas stay bit-identical.  Validation runs on every rank (same numbers, same stopping)."""
+    after dist.all_gather_tuples), `data_parallel` splits each batch: every rank draws the SAME batch_size indices (one
+    sampling stream shared by the ranks: `generator`, or one seeded by a number rank 0 broadcasts) and takes every
+    world-th of them, the flattened gradients (1.9 MB) are averaged with one all-reduce per iteration, and every rank takes
+    the same optimizer step - the replicas stay bit-identical and one iteration sees batch_size distinct draws, as in a
+    single process.  Validation runs on every rank (same numbers, same stopping)."""
     import torch.distributed as tdist
     world = tdist.get_world_size(group) if (data_parallel and tdist.is_available() and tdist.is_initialized()) else 1
-    if world > 1:
-        batch_size = max(1, batch_size // world)
+    my_rank = tdist.get_rank(group) if world > 1 else 0
+    if world > 1 and generator is None:
+        seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(data[0].device)
+        tdist.broadcast(seed, src=tdist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        generator = torch.Generator(device=data[0].device).manual_seed(int(seed.item()))
     n = data[0].shape[0]
     n_val = int(n * validation_fraction)
     data = list(data)
@@ -129,6 +137,8 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
             idx = torch.randint(0, n - n_val, (batch_size,), device=data[0].device, generator=generator)
         else:
             idx = torch.randperm(n - n_val, device=data[0].device, generator=generator)[:batch_size]
+        if world > 1:
+            idx = idx[my_rank::world]
         optimizer.zero_grad(set_to_none=True)
         loss, _ = batch_loss(net, [d[idx] for d in train], weighted)
         loss.backward()
