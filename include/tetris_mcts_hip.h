@@ -72,6 +72,8 @@ enum {
 #define TM_KIND_CPPAGENT_LP 2  /* agent.cpp:420-436,517-566     : float carry, end_obs[o], no gamma^2       */
 #define TM_KIND_CPPAGENT 3     /* agent.cpp:437-446,496-513     : float carry, single leaf                 */
 #define TM_KIND_VANILLA 4      /* agents/Vanilla.py:42-64       : random rollout to the end of the game (CPython MT19937 randint), variance 1e3 */
+#define TM_KIND_VANILLA_C 5    /* agents/VanillaC.py:5-14 via agent.cpp:447-455 (evaluator type 1): rollout with randint(0, 7),
+                                  variance 1e5, float carry, the C++ agent's root statistics */
 
 typedef struct tm_store {
     /* sizes */
@@ -117,7 +119,7 @@ typedef struct tm_store {
     uint32_t *replay_obs; /* [G][replay_cap][12] */
     float *replay_stat;   /* [G][replay_cap][4] value, variance, visit, 0 */
     int32_t *replay_count;/* [G] */
-    uint32_t *mt_state;   /* [G][625] CPython random state per game (624 words + index), TM_KIND_VANILLA rollouts (Vanilla.py:4,52) */
+    uint32_t *mt_state;   /* [G][625] CPython random state per game (624 words + index), TM_KIND_VANILLA / TM_KIND_VANILLA_C rollouts (Vanilla.py:4,52) */
     uint32_t *node_child; /* [G][N][8] raw child[7] per action (agents/agent.py:61) + pad */
 } tm_store;
 

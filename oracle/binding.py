@@ -130,7 +130,8 @@ class Game:
 
 
 class Agent:
-    """Oracle tree agent. kind: 0 ValueSim, 1 ValueSimLP, 2 all-C++ agent LP, 3 all-C++ agent single, 4 Vanilla."""
+    """Oracle tree agent. kind: 0 ValueSim, 1 ValueSimLP, 2 all-C++ agent LP, 3 all-C++ agent single, 4 Vanilla,
+    5 VanillaC (the all-C++ agent with evaluator type 1 = random playout)."""
 
     def __init__(self, kind, max_nodes=100000, app=1, scoring=0, randomizer=0, gamma=0.999, low=1, benchmark=False,
                  online=False, min_visits_to_store=None, memory_size=0, evaluator="hash", params=None,
@@ -160,7 +161,7 @@ class Agent:
         if cpp_occupied:
             # the reference C++ agent's `occupied` vector slip (agent.cpp:300-301, see agent_oracle.c); only where the
             # oracle is compared with the reference's compiled agent, never where it checks the product
-            assert kind in (2, 3)
+            assert kind in (2, 3, 5)
             L.orc_agent_set_cpp_occupied(self.h, 1)
 
     def set_python_random_state(self, state):

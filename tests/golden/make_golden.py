@@ -432,6 +432,40 @@ def gen_agents_env():
         json.dump(out, f)
 
 
+def gen_vanillac():
+    """The reference's VanillaC (agents/VanillaC.py: the compiled MCTSAgent with evaluator type 1 = a Python random playout
+    of a copy of the leaf, `game.play(randint(0, 7))`, variance 1e5, gamma 0.99) on the oracle engine."""
+    import random
+    ref_shims.install()
+    from pyTetris import Tetris
+    agent_mod = sys.modules["agents.cppmodule.agent"]
+
+    def random_playout(game):               # agents/VanillaC.py:5-8, verbatim semantics
+        while not game.end:
+            game.play(random.randint(0, 7))
+        return game.score, 1e5
+    out = []
+    for sims, max_nodes, seed, rseed, moves in ((100, 60000, 51, 0, 40), (40, 40000, 53, 9, 120), (30, 3000, 52, 5, 150)):
+        ref_shims.srand(1)
+        random.seed(rseed)
+        agent = agent_mod.MCTSAgent(sims, max_nodes, True, 0.99, False, random_playout, 1, False)
+        game = Tetris((20, 10), 1, 0, 0, seed)
+        agent.update_root(game)
+        rec = []
+        for _ in range(moves):
+            a = int(agent.play())
+            game.play(a)
+            agent.update_root(game)
+            rec.append([a, int(game.score), int(game.line_clears)])
+            if game.end:
+                game.reset()
+                agent.update_root(game)
+        out.append(dict(sims=sims, max_nodes=max_nodes, seed=seed, random_seed=rseed, moves=rec))
+        print("VanillaC sims %d moves %d final score %d lines %d" % (sims, len(rec), rec[-1][1], rec[-1][2]))
+    with open(os.path.join(OUT, "ref_vanillac.json"), "w") as f:
+        json.dump(out, f)
+
+
 def _legacy_torch_overloads():
     """model/yogi.py and model/model_vv.py call `add(number, tensor)`, `add_(number, tensor)`, `addcmul_(number, t, t)` and
     `addcdiv_(number, t, t)`, signatures PyTorch removed after 1.x.  Re-add them (number first = `alpha` / `value`) so the
@@ -531,7 +565,7 @@ def gen_training():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training", "vanillac"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -551,6 +585,8 @@ if __name__ == "__main__":
         gen_agents_env()
     if "training" in which:
         gen_training()
+    if "vanillac" in which:
+        gen_vanillac()
     if "agents" in which:
         if params is None:
             params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]

@@ -388,3 +388,63 @@ def test_online_cpp_agent_training_sets(oracle, golden_dir, idx):
         # episode-driven policies train at the same moves as the reference's own run (the slip only changes how many
         # tuples a GC yields, which moves the memory-driven policies 2 and 3)
         assert [c["move"] for c in got_calls] == [c["move"] for c in r["train_calls"]]
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_reference_vanillac_golden_runs(golden_dir, idx):
+    """tests/golden/ref_vanillac.json: the reference's VanillaC = compiled MCTSAgent, evaluator type 1 (agent.cpp:447-455),
+    agents/VanillaC.py's playout (randint(0, 7), variance 1e5, gamma 0.99).  Runs 0 and 1 stay inside their pools; run 2 of
+    the file goes through collections, where the compiled agent's `occupied` slip changes what
+    survives - that one is replayed by the oracle with the slip modelled (tests/test_oracle_agent.py), and the product is
+    checked through collections against the oracle without it (test_vanillac_batch_vs_oracle)."""
+    from tetris_mcts_amd import agents
+    from tetris_mcts_amd.pyTetris import Tetris
+    with open(os.path.join(golden_dir, "ref_vanillac.json")) as f:
+        r = json.load(f)[idx]
+    game = Tetris((20, 10), 1, 0, 0, seed=r["seed"], n_games=1)
+    agent = agents.VanillaC(sims=r["sims"], env=Tetris, env_args=game.env_args, n_games=1, max_nodes=r["max_nodes"],
+                            random_seed=r["random_seed"])
+    agent.update_root(game)
+    for i, (act, score, lines) in enumerate(r["moves"]):
+        got = agent.play()
+        assert got == act, (i, got, act)
+        game.play(got)
+        agent.update_root(game)
+        assert (game.score, game.line_clears) == (score, lines), i
+        if game.end:
+            game.reset()
+            agent.update_root(game)
+
+
+def test_vanillac_batch_vs_oracle(oracle):
+    import random
+    from tetris_mcts_amd import agents
+    from tetris_mcts_amd.pyTetris import Tetris
+    G, sims, mn = 6, 30, 5000
+    game = Tetris((20, 10), 1, 0, 0, seed=60, n_games=G)
+    agent = agents.VanillaC(sims=sims, env=Tetris, env_args=game.env_args, n_games=G, max_nodes=mn, random_seed=3)
+    agent.update_root(game)
+    og = [oracle.Game(seed=60 + g) for g in range(G)]
+    oa = [oracle.Agent(5, max_nodes=mn, gamma=0.99, low=1) for _ in range(G)]
+    for g in range(G):
+        oa[g].set_python_random_state(random.Random(3 + g).getstate())
+        oa[g].update_root(og[g])
+    for m in range(90):
+        act = agent.play()
+        stats = agent.get_stats()
+        for g in range(G):
+            a = oa[g].play(sims)
+            assert a == act[g], (m, g)
+            assert oa[g].stats().tobytes() == stats[g].tobytes(), (m, g)
+            og[g].play(a)
+            oa[g].update_root(og[g])
+        game.play(act)
+        agent.update_root(game)
+        ended = game.end
+        if ended.any():
+            game.reset("ended")
+            agent.update_root(game)
+            for g in np.nonzero(ended)[0]:
+                og[g].reset()
+                oa[g].update_root(og[g])
+    assert agent.store.counter("N_GC") == sum(o.n_gc for o in oa) >= 1

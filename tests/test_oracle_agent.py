@@ -167,3 +167,27 @@ def test_agent_oracle_replays_reference_other_environments(oracle, golden_dir, i
             g.reset()
             a.update_root(g)
     a.close()
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_agent_oracle_replays_reference_vanillac(oracle, golden_dir, idx):
+    """tests/golden/ref_vanillac.json: the reference's VanillaC = the compiled MCTSAgent with evaluator type 1
+    (agent.cpp:447-455) and agents/VanillaC.py's random playout (randint(0, 7), variance 1e5), gamma 0.99."""
+    import random
+    with open(os.path.join(golden_dir, "ref_vanillac.json")) as f:
+        r = json.load(f)[idx]
+    g = oracle.Game(seed=r["seed"])
+    a = oracle.Agent(5, max_nodes=r["max_nodes"], gamma=0.99, low=1, cpp_occupied=True)   # the compiled agent's GC slip (DESIGN.md section 6)
+    a.set_python_random_state(random.Random(r["random_seed"]).getstate())
+    a.update_root(g)
+    for i, (act, score, lines) in enumerate(r["moves"]):
+        got = a.play(r["sims"])
+        assert got == act, (i, got, act)
+        g.play(got)
+        a.update_root(g)
+        assert (g.score, g.line_clears) == (score, lines), i
+        if g.end:
+            g.reset()
+            a.update_root(g)
+    assert a.n_gc >= (1 if idx == 2 else 0)
+    a.close()

@@ -71,7 +71,7 @@ int tm_store_slice(const tm_store* s, int first, int n, tm_store* out) {
     if (t.replay_obs) t.replay_obs += f * (size_t)s->replay_cap * TM_OBS_DW;
     if (t.replay_stat) t.replay_stat += f * (size_t)s->replay_cap * 4;
     if (t.replay_count) t.replay_count += f;
-    if (t.mt_state && s->kind == TM_KIND_VANILLA) t.mt_state += f * 625;
+    if (t.mt_state && (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)) t.mt_state += f * 625;
     *out = t;
     return 0;
 }

@@ -50,6 +50,12 @@ __device__ inline int mt_randint7(MtLds& m) {
     while (r >= 7) r = mt_next(m) >> 29;
     return (int)r;
 }
+// random.randint(0, 7) (agents/VanillaC.py:7) = _randbelow_with_getrandbits(8): 8.bit_length() = 4 bits, rejection of r >= 8
+__device__ inline int mt_randint8(MtLds& m) {
+    uint32_t r = mt_next(m) >> 28;
+    while (r >= 8) r = mt_next(m) >> 28;
+    return (int)r;
+}
 
 // Base pointers of one game, computed where they are used (g is wave-uniform, so each is a few scalar instructions):
 // holding all fifteen of them in scalar registers for the whole kernel made the tree walk's loop reload spilled ones.
@@ -586,12 +592,15 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
     const int k = P.gs()[TM_GS_K_EVAL];
     const int leaf_score = P.gs()[TM_GS_LEAF_SCORE];
     const int kind = S.kind;
-    const bool fcarry = (kind == TM_KIND_CPPAGENT_LP || kind == TM_KIND_CPPAGENT);
+    const bool fcarry = (kind == TM_KIND_CPPAGENT_LP || kind == TM_KIND_CPPAGENT || kind == TM_KIND_VANILLA_C);
     double v0 = 0, var0 = 0;
     bool seq = false;
     if (kind == TM_KIND_VANILLA) {
         v0 = (double)leaf_score;   // the rollout's final score (or the terminal leaf's own), Vanilla.py:54,59
         var0 = leaf_end ? 0.0 : 1e3;
+    } else if (kind == TM_KIND_VANILLA_C) {
+        v0 = (double)(float)leaf_score;   // agent.cpp:452-454: float _val = (game.score, 1e5)[0]; terminal leaf: (float)games[leaf].score
+        var0 = leaf_end ? 0.0 : 1e5;
     } else if (kind == TM_KIND_VALUESIM) {
         v0 = (double)leaf_score;   // Python int score + np.float32 v under numpy 1.17 = float64
         if (!leaf_end) { v0 = v0 + (double)P.eval_v()[0]; var0 = (double)P.eval_var()[0]; }
@@ -815,7 +824,11 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
             EngCfg cfg{S.app, S.scoring, S.randomizer};
             Piece p;
             load_fields(L.slots[7], p);
-            while (!(p.flags & 1)) play(reinterpret_cast<uint16_t*>(L.slots[7]), p, cfg, mt_randint7(*M), nullptr);
+            // Vanilla.py:52 draws randint(0, 6); VanillaC.py:7 randint(0, 7) (action 7 does nothing but let gravity act)
+            if (S.kind == TM_KIND_VANILLA_C)
+                while (!(p.flags & 1)) play(reinterpret_cast<uint16_t*>(L.slots[7]), p, cfg, mt_randint8(*M), nullptr);
+            else
+                while (!(p.flags & 1)) play(reinterpret_cast<uint16_t*>(L.slots[7]), p, cfg, mt_randint7(*M), nullptr);
             L.misc[60] = (uint32_t)p.score;
         }
         wave_sync();
@@ -1199,7 +1212,7 @@ __global__ void k_root_stats(tm_store S, float* stats, int32_t* action) {
     const int root = P.gs()[TM_GS_ROOT];
     float self = __uint_as_float(P.rec()[(size_t)root * TM_REC_DW + TM_REC_SCORE]);
     float* out = stats + (size_t)g * 21;
-    const bool cpp = (S.kind == TM_KIND_CPPAGENT_LP || S.kind == TM_KIND_CPPAGENT);
+    const bool cpp = (S.kind == TM_KIND_CPPAGENT_LP || S.kind == TM_KIND_CPPAGENT || S.kind == TM_KIND_VANILLA_C);
     int best = 0, first_nan = -1;
     float bestv = 0;
     for (int a = 0; a < 7; ++a) {
@@ -1424,7 +1437,7 @@ int tm_update_root(const tm_store* s, void* stream) {
 }
 int tm_sim_step(const tm_store* s, int flags, void* stream) {
     const dim3 grid((s->n_games + WPB - 1) / WPB), block(64 * WPB);
-    if (s->kind == TM_KIND_VANILLA)
+    if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
         hipLaunchKernelGGL(k_sim_step<true>, grid, block, WPB * sizeof(MtLds), (hipStream_t)stream, *s, flags);
     else
         hipLaunchKernelGGL(k_sim_step<false>, grid, block, 0, (hipStream_t)stream, *s, flags);

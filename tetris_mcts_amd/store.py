@@ -11,7 +11,7 @@ import torch
 from . import _lib
 
 SIM_BACKUP, SIM_FRONT = 1, 2
-KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA = 0, 1, 2, 3, 4
+KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA, KIND_VANILLA_C = 0, 1, 2, 3, 4, 5
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18, MAX_TRACE=19, N_DROPPED=25,
           CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_SLICES=38,
@@ -71,7 +71,7 @@ class TreeStore:
             gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N),
             replay_obs=z(G, max(replay_cap, 1), 12), replay_stat=z(G, max(replay_cap, 1), 4, dtype=torch.float32),
             replay_count=z(G),
-            mt_state=z(G if kind == KIND_VANILLA else 1, 625),
+            mt_state=z(G if kind in (KIND_VANILLA, KIND_VANILLA_C) else 1, 625),
         )
         self.t["nq_table"] = norm_quantile_table(nq_size, dev)
         s = _lib.TmStore()
