@@ -37,3 +37,36 @@ def test_env_step_matches_oracle(oracle, app, scoring, rnd):
                     ora[g].reset()
     assert sum(o.line_clears for o in ora) >= 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("app,scoring", [(1, 0), (2, 1), (3, 0)])
+def test_state_injection_sweep(oracle, app, scoring):
+    """Every piece x orientation x valid position (resting, one above, near the top) on crafted boards (1-4 nearly full
+    rows with wells, stairs, walls, a high shaft, random junk), every drop counter, both back-to-back states: each state
+    is injected into the device games and stepped with each of the actions 0..7, HIP vs oracle, whole packed game and
+    line statistics.  Covers singles to tetrises, back-to-back, combo counting, wall / floor kicks, the skipped upward
+    kicks, locks by gravity and by a blocked soft drop, top-outs at spawn."""
+    import torch
+    from engine_cases import sweep_states
+    from tetris_mcts_amd.pyTetris import Tetris
+    recs = sweep_states(oracle, app)
+    n = len(recs)
+    L = oracle.lib()
+    env = Tetris((20, 10), app, scoring, 0, seed=1, n_games=n)
+    cleared = np.zeros(5, np.int64)
+    for a in range(8):
+        env.games.copy_(torch.from_numpy(recs.view(np.int32).reshape(n, 16).copy()))
+        env._ls.zero_()
+        env.play(np.full(n, a, np.int32))
+        got = env.packed()
+        got_ls = env._ls.cpu().numpy()
+        exp = recs.copy()
+        exp_ls = np.zeros((n, 4), np.int32)
+        for i in range(n):
+            L.orc_game_play(oracle.ptr(exp[i:i + 1]), app, scoring, 0, a, oracle.ptr(exp_ls[i]))
+        expw = exp.view(np.uint32).reshape(n, 16)
+        bad = np.nonzero((got != expw).any(axis=1))[0]
+        assert len(bad) == 0, (a, len(bad), recs[bad[0]], got[bad[0]], expw[bad[0]])
+        assert np.array_equal(got_ls, exp_ls)
+        cleared[1:] += exp_ls.sum(axis=0)
+    assert (cleared[1:] > 0).all(), cleared         # singles, doubles, triples and tetrises all occurred
