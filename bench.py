@@ -220,6 +220,7 @@ def main():
                       "of every game); the learning curve (lines cleared per episode vs training round) is "
                       "scripts/selfplay_online.py -> profiles/*_online_learning.jsonl" % (args.warmup + 1, args.warmup + args.steps),
         "error_games": int(err),
+        "walk_mispredicted_levels": S.counter("N_WALK_MISS") / max(S.counter("TRACE_SUM"), 1),
         "gc": {"collections": int(n_gc), "slices": int(gc_slices), "catchup_launches": int(catchup),
                "dropped_tuples": int(dropped)},
         "store_gib_per_gpu": S.nbytes() / 2**30,

@@ -25,7 +25,8 @@ extern "C" {
 #define TM_OBS_DW 12       /* packed observation, ENGINE_SPEC.md section 7 (48 bytes) */
 #define TM_REC_DW 32       /* node record (128 bytes = one cache line): eight 16-byte pieces.  Pieces 0..6 = the node's unique
                               children in selection order: (child, obs, child score bits, own score bits); piece 7 =
-                              (0, TM_REC_OBS, TM_REC_SCORE, TM_REC_HDR); see DESIGN.md "node store" */
+                              (TM_REC_PCHILD, TM_REC_OBS, TM_REC_SCORE, TM_REC_HDR); see DESIGN.md "node store" */
+#define TM_REC_PCHILD 28   /* the child the last walk through this node descended into (0: none yet): the walk prefetches it */
 #define TM_REC_OBS 29      /* node_to_obs */
 #define TM_REC_SCORE 30    /* float32 score of the node's game */
 #define TM_REC_HDR 31      /* bits 0-2 number of unique children, bit 24 game ended, bit 25 expanded */
@@ -59,7 +60,8 @@ enum {
     /* per-move simulation quota: tm_move_begin adds `sims` to the target; a launch starts a simulation for a game only
        while started < target, so games that lost launches to a collection catch up in extra launches (tm_sims_remaining) */
     TM_GS_SIM_TARGET = 40, TM_GS_SIM_STARTED,
-    TM_GS_CYC_WALK_MEM   /* profiling builds (-DTM_PROF_WALK): cycles of the last walk spent waiting for its loads */
+    TM_GS_CYC_WALK_MEM,  /* profiling builds (-DTM_PROF_WALK): cycles of the last walk spent waiting for its loads */
+    TM_GS_N_WALK_MISS    /* tree levels at which the walk descended into another child than the predicted one (all simulations) */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
@@ -107,7 +109,7 @@ typedef struct tm_store {
     uint32_t *rng;        /* [G][32] glibc rand() state (31 words) per game (core.h:62,76) */
     uint32_t *env_game;   /* [G][16] the real games */
     int32_t *env_line_stats; /* [G][4] */
-    uint32_t *trace;      /* [G][max_trace][4] node, obs, score bits, 0 */
+    uint32_t *trace;      /* [G][max_trace][2] (observation, score bits) of the nodes of the walk in flight; max_trace % 64 == 0 */
     int32_t *leaf;        /* [G][32] unique children of the leaf: node[7], obs[7], score bits[7], end[7] */
     int32_t *eval_obs;    /* [G*eval_slots] observation index inside the game's pool, 0 = unused slot */
     float *eval_v;        /* [G*eval_slots] evaluator outputs */

@@ -24,7 +24,8 @@ struct WaveLds {
     uint32_t slots[8][GAME_DW];  // 0..6 successor games, 7 the parent
     uint32_t okeys[7][OBS_DW];
     uint32_t misc[64];
-    uint4 tbuf[TRACE_LDS];       // (node, obs, score bits, 0) of the walk in progress
+    uint2 tbuf[TRACE_LDS];       // (observation, score bits) of the nodes of the walk in progress
+    uint2 tdummy[64];            // where the lanes that do not own the trace put their (ignored) copy: no exec masking in the walk
 };
 struct MtLds { uint32_t mt[624]; uint32_t idx; uint32_t pad[3]; };   // CPython random state (TM_KIND_VANILLA)
 
@@ -77,7 +78,7 @@ struct GP {
     __device__ __forceinline__ int32_t* eval_obs() const { return S.eval_obs + (size_t)g * S.eval_slots; }
     __device__ __forceinline__ float* eval_v() const { return S.eval_v + (size_t)g * S.eval_slots; }
     __device__ __forceinline__ float* eval_var() const { return S.eval_var + (size_t)g * S.eval_slots; }
-    __device__ __forceinline__ uint32_t* trace() const { return S.trace + (size_t)g * (size_t)S.max_trace * 4; }
+    __device__ __forceinline__ uint32_t* trace() const { return S.trace + (size_t)g * (size_t)S.max_trace * 2; }
 };
 
 __device__ __forceinline__ GP game_ptrs(const tm_store& S, int g) { return GP{S, g}; }
@@ -517,12 +518,12 @@ __device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lan
     for (int base = 0; base < len; base += 64) {
         int cnt = min(64, len - base);
         int i = len - 1 - base - lane;
-        uint4 e = make_uint4(0, 0, 0, 0);
-        if (lane < cnt) e = reinterpret_cast<const uint4*>(P.trace())[i];
+        uint2 e = make_uint2(0, 0);      // (observation, score bits)
+        if (lane < cnt) e = reinterpret_cast<const uint2*>(P.trace())[i];
         double x = 0;
         float xf = 0;
         for (int j = 0; j < cnt; ++j) {
-            float sj = rl_f32(__uint_as_float(e.z), j);   // wave-uniform source lane
+            float sj = rl_f32(__uint_as_float(e.y), j);   // wave-uniform source lane
             if (float_carry) {
                 Vf = Vf - sj;
                 if (lane == j) xf = Vf;
@@ -536,7 +537,7 @@ __device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lan
             }
         }
         if (lane < cnt) {
-            uint32_t* st = P.stat() + (size_t)e.y * 4;
+            uint32_t* st = P.stat() + (size_t)e.x * 4;
             if (float_carry) welford_f32carry(st, xf, varf);
             else welford_f64(st, x, var0);
         }
@@ -549,9 +550,9 @@ __device__ inline void lane_backup_trace_seq(const tm_store& S, const GP& P, int
     double V = v0;
     float Vf = (float)v0;
     for (int i = len - 1; i >= 0; --i) {
-        uint4 e = reinterpret_cast<const uint4*>(P.trace())[i];
-        float sj = __uint_as_float(e.z);
-        uint32_t* st = P.stat() + (size_t)e.y * 4;
+        uint2 e = reinterpret_cast<const uint2*>(P.trace())[i];
+        float sj = __uint_as_float(e.y);
+        uint32_t* st = P.stat() + (size_t)e.x * 4;
         if (float_carry) {
             Vf = Vf - sj;
             welford_f32carry(st, Vf, (float)var0);
@@ -572,9 +573,9 @@ __device__ inline bool trace_has_repeat(const GP& P, int lane, int len, const in
     bool rep = false;
     for (int base = 0; base < len; base += 64) {
         int i = base + lane;
-        uint32_t oi = (i < len) ? P.trace()[(size_t)i * 4 + 1] : 0xFFFFFFFFu;
+        uint32_t oi = (i < len) ? P.trace()[(size_t)i * 2] : 0xFFFFFFFFu;
         for (int j = 0; j < len; ++j) {
-            uint32_t oj = P.trace()[(size_t)j * 4 + 1];
+            uint32_t oj = P.trace()[(size_t)j * 2];
             if (i < len && j != i && oj == oi) rep = true;
         }
         for (int j = 0; j < n_extra; ++j)
@@ -717,93 +718,147 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     int nq_fallback = 0;
     bool overflow = false;
     // Node record = eight 16-byte pieces: pieces 0..6 are the unique children in selection order (child, observation,
-    // child score, own score), piece 7 is (0, own observation, own score, header).  The wave is eight 8-lane groups:
-    // every lane of group j holds piece j of the current node, so group j owns unique child j.  Per level ONE round
-    // of loads: lane (j, t) loads the statistics of observation j (16 B, the same address in the whole group) and,
-    // speculatively, piece t of child j's record - whichever child is selected, its record is already in registers
-    // and four ds_bpermute move piece j' of it into group j'.  Empty slots and group 7 carry child 0 / observation 0
-    // (the null entries, always valid addresses).  Nothing is stored to global memory inside the walk (stores share the
-    // load counter on gfx9); the trace goes through LDS and is flushed 64 entries at a time with coalesced stores.
+    // child score, own score), piece 7 is (predicted child, own observation, own score, header).  The wave is eight
+    // 8-lane groups: every lane of group j holds piece j of the current node, so group j owns unique child j.
+    //
+    // The walk is a dependent chain (the child to descend into is known only after the children's statistics are
+    // here), so it is software-pipelined on a PREDICTION: every node remembers the slot its last walk took (header
+    // bits 4-6) and that child's index (piece 7, word 0).  One round of loads per level fetches the statistics of the
+    // node's children AND the predicted child's record - piece j straight into group j, where it will be needed - and as
+    // soon as that record is here the NEXT level's round (the predicted child's children's statistics, its own predicted
+    // child) is issued, BEFORE this level's selection arithmetic.  The arithmetic (check_low / policy_clt, unchanged, on
+    // the true statistics) then runs under the next level's memory latency.  If it selects another child than the
+    // predicted one (a few per cent of the levels; always at a freshly expanded node), the speculative loads are dropped,
+    // the node's prediction is rewritten and the walk pays one extra round trip.  Results do not depend on predictions.
+    // Nothing else is stored to global memory inside the walk (stores share the load counter on gfx9); the trace goes
+    // through LDS and is flushed 64 entries at a time with coalesced stores.
     const int grp = lane >> 3;
-    const uint32_t pc16 = (uint32_t)(lane & 7) * 16u;
-    const int grp4 = grp * 4;
+    const uint32_t grp16 = (uint32_t)grp * 16u;
     const __amdgpu_buffer_rsrc_t rec_rs = make_rsrc(P.rec(), P.n() * (TM_REC_DW * 4u));
     const __amdgpu_buffer_rsrc_t stat_rs = make_rsrc(P.stat(), P.n() * 16u);
-    uint4 cur = buf_ld16(rec_rs, (uint32_t)idx * (TM_REC_DW * 4u) + (uint32_t)grp * 16u);
+    // per-lane constants of the loop: the visit mask drops the end flag and makes group 7 (the node's own piece, whose
+    // statistics load is the node's own observation) count as "no child"; a NaN score wins at slot 0 and loses elsewhere
+    const uint32_t vmask = lane < 56 ? 0x7FFFFFFFu : 0u;
+    const int nan_key = grp == 0 ? 0x7FFFFFFF : (int)0x80000000;
+    const uint64_t lanes_lt56 = 0x00FFFFFFFFFFFFFFull;
+    // trace: lane 56 (group 7 holds the node's own observation and score) appends 8 bytes per level; the other lanes
+    // store theirs to a dummy slot, so the walk needs no exec masking for it
+    uint2* tp = (lane == 56) ? &L.tbuf[0] : &L.tdummy[lane];
+    const int tinc = (lane == 56) ? 1 : 0;
     int flushed = 0;
-    auto flush_trace = [&](int upto) {   // entries [flushed, upto) from LDS to global, 64 per pass
+    auto flush_trace = [&](int upto) {   // entries [flushed, upto) from LDS to global, coalesced
         for (int base = flushed; base < upto; base += 64) {
             int i = base + lane;
-            if (i < upto) reinterpret_cast<uint4*>(P.trace())[i] = L.tbuf[i - flushed];
+            if (i < upto) reinterpret_cast<uint2*>(P.trace())[i] = L.tbuf[i - flushed];
         }
         flushed = upto;
     };
-    // wave-uniform index into a table nobody writes: constant address space = one s_load_dword through the scalar cache
-    typedef const float __attribute__((address_space(4))) * const_f32_ptr;
-    const const_f32_ptr nqt = (const_f32_ptr)(uintptr_t)S.nq_table;
+    // (float)norm_quantile(n): wave-uniform index into a table nobody writes = one s_load_dword (scalar cache) at a
+    // 32-bit offset; the inline form keeps the address arithmetic to one shift
+    const uint64_t nq_base = (uint64_t)(uintptr_t)S.nq_table;
     const int nq_size = S.nq_size, max_trace = S.max_trace;
+    int n_miss = 0;
 #ifdef TM_PROF_WALK
     long long prof_mem = 0;
 #endif
-    for (;;) {
-        if (len >= max_trace) { overflow = true; break; }
-        if (len - flushed == TRACE_LDS) { wave_sync(); flush_trace(len); wave_sync(); }
-        if (lane == 56) L.tbuf[len - flushed] = make_uint4((uint32_t)idx, cur.y, cur.z, 0u);   // group 7: own observation, own score
-        len += 1;
-        const bool on = cur.x != 0u;
-        if (__ballot(on) == 0ull) break;          // no children: a leaf
-        // the loads of this level
-#ifdef TM_PROF_WALK
-        const long long tpa = __builtin_readcyclecounter();
-#endif
-        const uint4 st = buf_ld16(stat_rs, cur.y * 16u);
-        const uint4 pf = buf_ld16(rec_rs, cur.x * (TM_REC_DW * 4u) + pc16);
-        const int visit = (int)(st.x & 0x7FFFFFFFu);
-#ifdef TM_PROF_WALK
-        asm volatile("" :: "v"(visit), "v"(pf.x));     // both loads have landed
-        prof_mem += __builtin_readcyclecounter() - tpa;
-#endif
-        const uint64_t lowmask = __ballot(on && visit < low);
-        int sel;
-        if (lowmask) {
-            // check_low (core.h:65-77): a uniformly drawn under-visited child, libc rand()
-            uint64_t mm = lowmask & 0x0101010101010101ull;      // one bit per group
-            const int m = __popcll(mm);
-            const uint32_t r = wave_rand(rs, rng_pos);
-            const int kth = (int)(r % (uint32_t)m);
-            for (int t = 0; t < kth; ++t) mm &= mm - 1;
-            sel = (__ffsll((long long)mm) - 1) >> 3;
-        } else {
-            // policy_clt (core.h:83-105): float arithmetic, one rounding per operation; the exploration term
-            // sqrtf(variance / (float)visit) was evaluated (with the same two operations) when the statistics changed.
-            const int n = (int)group_sum_u32(on ? (uint32_t)visit : 0u);     // n = sum of the children's visits
-            float coeff;
-            if (n < nq_size) coeff = nqt[n];
-            else { coeff = norm_quantile_dev((double)n); nq_fallback += 1; }
-            const float t1 = __uint_as_float(st.y) + __uint_as_float(cur.z);
-            const float val = t1 - __uint_as_float(cur.w);
-            const float prod = coeff * __uint_as_float(st.w);
-            const float q = val + prod;
-            // first-max argmax with the reference's scan semantics (max_q = q_0; i >= 1 replaces only if q_i > max_q):
-            // a NaN at i >= 1 never wins, a NaN at 0 is never replaced, ties keep the lower index.  Compared as
-            // order-preserving integer keys (-0 folded into +0, as the float compare treats them as equal).
-            uint32_t qb = __float_as_uint(q);
-            qb = (qb == 0x80000000u) ? 0u : qb;
-            int key = (int)(qb ^ (((uint32_t)((int)qb >> 31)) >> 1));
-            if (q != q) key = (grp == 0) ? 0x7FFFFFFF : (int)0x80000000;
-            key = on ? key : (int)0x80000000;
-            const int kmax = group_max_i32(key);
-            sel = (__ffsll((long long)__ballot(key == kmax)) - 1) >> 3;
-        }
-        idx = (int)rl_u32(cur.x, sel * 8);
-        {   // piece j of the selected child's record sits in lane 8*sel + j of the prefetched block
-            const int src = sel * 32 + grp4;
-            cur.x = bperm_u32(src, pf.x);
-            cur.y = bperm_u32(src, pf.y);
-            cur.z = bperm_u32(src, pf.z);
-            cur.w = bperm_u32(src, pf.w);
-        }
+    // three record register sets and two statistics sets rotate through the roles (current node, predicted child,
+    // predicted grandchild) / (this level, next level): the loop body is instantiated six times instead of moving
+    // eleven registers per level.  p0..p2 = predicted child (piece 7, word 0) of the node held in r0..r2.
+    uint4 r0 = buf_ld16(rec_rs, (uint32_t)idx * (TM_REC_DW * 4u) + grp16), r1, r2;
+    uint32_t p0 = rl_u32(r0.x, 56), p1 = 0, p2 = 0;
+    uint4 s0 = buf_ld16(stat_rs, r0.y * 16u), s1 = s0;
+    r1 = buf_ld16(rec_rs, p0 * (TM_REC_DW * 4u) + grp16);
+    r2 = r1;
+    uint4 last = r0;         // the record of the node the walk ended at
+    bool done = false;
+#define TM_WALK_LEVEL(RC, PC, SC, RN, PN, SN, RNN)                                                                      \
+    if (!done) {                                                                                                        \
+        if ((len & (TRACE_LDS - 1)) == 0 && len != 0) {                                                                 \
+            if (len >= max_trace) { overflow = true; done = true; last = RC; }                                          \
+            else { wave_sync(); flush_trace(len); wave_sync(); if (lane == 56) tp = &L.tbuf[0]; }                       \
+        }                                                                                                               \
+    }                                                                                                                   \
+    if (!done) {                                                                                                        \
+        *tp = make_uint2(RC.y, RC.z);                                                                                   \
+        tp += tinc;                                                                                                     \
+        len += 1;                                                                                                       \
+        const uint64_t onm = __builtin_amdgcn_ballot_w64(RC.x != 0u) & lanes_lt56;                                      \
+        if (onm == 0ull) { done = true; last = RC; }        /* no children: a leaf */                                   \
+        else {                                                                                                          \
+            TM_WALK_PROF(SC, RN)                                                                                        \
+            /* the next level's round of loads, on the assumption that the predicted child is the one */               \
+            PN = rl_u32(RN.x, 56);                                                                                      \
+            SN = buf_ld16(stat_rs, RN.y * 16u);                                                                         \
+            RNN = buf_ld16(rec_rs, PN * (TM_REC_DW * 4u) + grp16);                                                      \
+            __builtin_amdgcn_sched_barrier(0);    /* keep their issue ahead of the arithmetic below */                  \
+            const int visit = (int)(SC.x & vmask);                                                                      \
+            const uint64_t lowmask = __builtin_amdgcn_ballot_w64(visit < low) & onm;                                    \
+            int sel;                                                                                                    \
+            if (lowmask) {                                                                                              \
+                /* check_low (core.h:65-77): a uniformly drawn under-visited child, libc rand() */                      \
+                uint64_t mm = lowmask & 0x0101010101010101ull;      /* one bit per group */                             \
+                const int m = __popcll(mm);                                                                             \
+                const uint32_t r = wave_rand(rs, rng_pos);                                                              \
+                const int kth = (int)(r % (uint32_t)m);                                                                 \
+                for (int t = 0; t < kth; ++t) mm &= mm - 1;                                                             \
+                sel = (__ffsll((long long)mm) - 1) >> 3;                                                                \
+            } else {                                                                                                    \
+                /* policy_clt (core.h:83-105): float arithmetic, one rounding per operation; the exploration term       \
+                   sqrtf(variance / (float)visit) was evaluated (same two operations) when the statistics changed.      \
+                   n = sum of the children's visits (empty slots read the null observation: 0 visits). */               \
+                const int n = (int)group_sum_u32((uint32_t)visit);                                                      \
+                float coeff;                                                                                            \
+                if (n < nq_size) {                                                                                      \
+                    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(coeff) : "s"(nq_base), "s"(n << 2)); \
+                } else { coeff = norm_quantile_dev((double)n); nq_fallback += 1; }                                      \
+                const float t1 = __uint_as_float(SC.y) + __uint_as_float(RC.z);                                         \
+                const float val = t1 - __uint_as_float(RC.w);                                                           \
+                const float prod = coeff * __uint_as_float(SC.w);                                                       \
+                const float q = (val + prod) + 0.0f;         /* -0 becomes +0 (the float compare treats them as equal) */ \
+                /* first-max argmax with the reference's scan semantics (max_q = q_0; i >= 1 replaces only if q_i >     \
+                   max_q): a NaN at i >= 1 never wins, a NaN at 0 is never replaced, ties keep the lower index.         \
+                   Compared as order-preserving integer keys. */                                                        \
+                const uint32_t qb = __float_as_uint(q);                                                                 \
+                int key = (int)(qb ^ (((uint32_t)((int)qb >> 31)) >> 1));                                               \
+                key = (q != q) ? nan_key : key;                                                                         \
+                key = (RC.x != 0u && lane < 56) ? key : (int)0x80000000;                                                \
+                const int kmax = group_max_i32(key);                                                                    \
+                sel = (__ffsll((long long)__builtin_amdgcn_ballot_w64(key == kmax)) - 1) >> 3;                          \
+            }                                                                                                           \
+            const uint32_t c = rl_u32(RC.x, sel * 8);                                                                   \
+            idx = (int)c;                                                                                               \
+            if (c != PC) {                                                                                              \
+                /* another child than the predicted one: remember it for the next walk through this node, fetch its     \
+                   record, restart the pipeline */                                                                      \
+                if (lane == 56) P.rec()[(size_t)cur_node * TM_REC_DW + TM_REC_PCHILD] = c;                              \
+                RN = buf_ld16(rec_rs, c * (TM_REC_DW * 4u) + grp16);                                                    \
+                PN = rl_u32(RN.x, 56);                                                                                  \
+                SN = buf_ld16(stat_rs, RN.y * 16u);                                                                     \
+                RNN = buf_ld16(rec_rs, PN * (TM_REC_DW * 4u) + grp16);                                                  \
+                n_miss += 1;                                                                                            \
+            }                                                                                                           \
+            cur_node = idx;                                                                                             \
+        }                                                                                                               \
     }
+#ifdef TM_PROF_WALK
+#define TM_WALK_PROF(SC, RN) { const long long tpa = __builtin_readcyclecounter(); asm volatile("" :: "v"(SC.x), "v"(RN.x)); \
+                               prof_mem += __builtin_readcyclecounter() - tpa; }
+#else
+#define TM_WALK_PROF(SC, RN)
+#endif
+    int cur_node = idx;
+    while (!done) {
+        TM_WALK_LEVEL(r0, p0, s0, r1, p1, s1, r2)
+        TM_WALK_LEVEL(r1, p1, s1, r2, p2, s0, r0)
+        TM_WALK_LEVEL(r2, p2, s0, r0, p0, s1, r1)
+        TM_WALK_LEVEL(r0, p0, s1, r1, p1, s0, r2)
+        TM_WALK_LEVEL(r1, p1, s0, r2, p2, s1, r0)
+        TM_WALK_LEVEL(r2, p2, s1, r0, p0, s0, r1)
+    }
+#undef TM_WALK_LEVEL
+#undef TM_WALK_PROF
+    idx = cur_node;
+    const uint4 cur = last;
     hdr = rl_u32(cur.w, 56);
     self_o = rl_u32(cur.y, 56);
     const uint32_t self_sc = rl_u32(cur.z, 56);
@@ -848,6 +903,7 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         if (len > gs[TM_GS_MAX_TRACE]) gs[TM_GS_MAX_TRACE] = len;
         if (nq_fallback) gs[TM_GS_N_NQ_FALLBACK] += nq_fallback;
         gs[TM_GS_SIM_STARTED] += 1;
+        gs[TM_GS_N_WALK_MISS] += n_miss;
 #ifdef TM_PROF_WALK
         gs[TM_GS_CYC_WALK_MEM] = (int)prof_mem;
 #endif

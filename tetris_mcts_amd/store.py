@@ -15,7 +15,7 @@ KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA, 
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18, MAX_TRACE=19, N_DROPPED=25,
           CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_SLICES=38,
-          SIM_TARGET=40, SIM_STARTED=41, CYC_WALK_MEM=42)
+          SIM_TARGET=40, SIM_STARTED=41, CYC_WALK_MEM=42, N_WALK_MISS=43)
 
 _nq_cache = {}
 
@@ -50,6 +50,8 @@ class TreeStore:
         shape, app, scoring, randomizer = env_args[0], env_args[1], env_args[2], env_args[3]
         if tuple(shape) != (20, 10):
             raise ValueError("only 20x10 boards are supported")
+        if max_trace % 64:
+            raise ValueError("max_trace must be a multiple of 64 (the walk flushes its LDS trace buffer every 64 levels)")
         self.L = _lib.lib()
         self.device = torch.device(device)
         self.n_games, self.max_nodes, self.kind = int(n_games), int(max_nodes), int(kind)
@@ -66,7 +68,7 @@ class TreeStore:
             node_rec=z(G, N, 32), node_child=z(G, N, 8), node_game=z(G, N, 16), obs_stat=z(G, N, 4), obs_key=z(G, N, 12),
             node_tab=z(G, cap, dtype=torch.int64), obs_tab=z(G, cap, dtype=torch.int64),
             free_node=z(G, N), free_obs=z(G, N), gs=z(G, 64), rng=z(G, 32), env_game=z(G, 16), env_line_stats=z(G, 4),
-            trace=z(G, max_trace, 4), leaf=z(G, 32), eval_obs=z(G * eval_slots),
+            trace=z(G, max_trace, 2), leaf=z(G, 32), eval_obs=z(G * eval_slots),
             eval_v=z(G * eval_slots, dtype=torch.float32), eval_var=z(G * eval_slots, dtype=torch.float32),
             gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N),
             replay_obs=z(G, max(replay_cap, 1), 12), replay_stat=z(G, max(replay_cap, 1), 4, dtype=torch.float32),
