@@ -109,7 +109,7 @@ typedef struct tm_store {
     uint32_t *rng;        /* [G][32] glibc rand() state (31 words) per game (core.h:62,76) */
     uint32_t *env_game;   /* [G][16] the real games */
     int32_t *env_line_stats; /* [G][4] */
-    uint32_t *trace;      /* [G][max_trace][2] (observation, score bits) of the nodes of the walk in flight; max_trace % 64 == 0 */
+    uint32_t *trace;      /* [G][max_trace][4] piece 7 of the record of every node of the walk in flight (word 1 observation, word 2 score bits); max_trace % 64 == 0 */
     int32_t *leaf;        /* [G][32] unique children of the leaf: node[7], obs[7], score bits[7], end[7] */
     int32_t *eval_obs;    /* [G*eval_slots] observation index inside the game's pool, 0 = unused slot */
     float *eval_v;        /* [G*eval_slots] evaluator outputs */

@@ -61,7 +61,7 @@ int tm_store_slice(const tm_store* s, int first, int n, tm_store* out) {
     t.rng += f * 32;
     if (t.env_game) t.env_game += f * TM_GAME_DW;
     if (t.env_line_stats) t.env_line_stats += f * 4;
-    t.trace += f * (size_t)s->max_trace * 2;
+    t.trace += f * (size_t)s->max_trace * 4;
     t.leaf += f * TM_LEAF_DW;
     t.eval_obs += f * (size_t)s->eval_slots;
     t.eval_v += f * (size_t)s->eval_slots;

@@ -24,8 +24,8 @@ struct WaveLds {
     uint32_t slots[8][GAME_DW];  // 0..6 successor games, 7 the parent
     uint32_t okeys[7][OBS_DW];
     uint32_t misc[64];
-    uint2 tbuf[TRACE_LDS];       // (observation, score bits) of the nodes of the walk in progress
-    uint2 tdummy[64];            // where the lanes that do not own the trace put their (ignored) copy: no exec masking in the walk
+    uint4 tbuf[TRACE_LDS];       // piece 7 (predicted child, observation, score bits, header) of the nodes of the walk in progress
+    uint4 tdummy[64];            // where the lanes that do not own the trace put their (ignored) copy: no exec masking in the walk
 };
 struct MtLds { uint32_t mt[624]; uint32_t idx; uint32_t pad[3]; };   // CPython random state (TM_KIND_VANILLA)
 
@@ -78,7 +78,7 @@ struct GP {
     __device__ __forceinline__ int32_t* eval_obs() const { return S.eval_obs + (size_t)g * S.eval_slots; }
     __device__ __forceinline__ float* eval_v() const { return S.eval_v + (size_t)g * S.eval_slots; }
     __device__ __forceinline__ float* eval_var() const { return S.eval_var + (size_t)g * S.eval_slots; }
-    __device__ __forceinline__ uint32_t* trace() const { return S.trace + (size_t)g * (size_t)S.max_trace * 2; }
+    __device__ __forceinline__ uint32_t* trace() const { return S.trace + (size_t)g * (size_t)S.max_trace * 4; }
 };
 
 __device__ __forceinline__ GP game_ptrs(const tm_store& S, int g) { return GP{S, g}; }
@@ -126,9 +126,12 @@ __device__ __forceinline__ uint32_t group_sum_u32(uint32_t v) {
     return rl_u32(v, 63);
 }
 __device__ __forceinline__ int group_max_i32(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xF, 0xF, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));
+    // v_max_i32 with a DPP source: lanes whose source lane is invalid or whose row is masked keep their value.  One
+    // instruction per stride (the builtin form costs a move, a DPP move and a max); 2 wait states between a VALU write
+    // and a DPP read of the same register.
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0" : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
@@ -147,6 +150,20 @@ __device__ __forceinline__ uint32_t wave_rand(uint32_t& rs, int& pos) {
     int f = pos & 0xFF, b = (pos >> 8) & 0xFF;
     uint32_t val = rl_u32(rs, f) + rl_u32(rs, b);
     rs = ((int)(threadIdx.x & 63) == f) ? val : rs;
+    f += 1;
+    if (f >= 31) { f = 0; b += 1; }
+    else { b += 1; if (b >= 31) b = 0; }
+    pos = f | (b << 8);
+    return val >> 1;
+}
+
+// the same on a copy of the state in LDS (L.misc[0..31]): the walk keeps no loop-carried vector register for it
+__device__ __forceinline__ uint32_t wave_rand_lds(uint32_t* r, int& pos, int lane) {
+    int f = pos & 0xFF, b = (pos >> 8) & 0xFF;
+    const uint32_t val = r[f] + r[b];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) r[f] = val;
+    __builtin_amdgcn_wave_barrier();
     f += 1;
     if (f >= 31) { f = 0; b += 1; }
     else { b += 1; if (b >= 31) b = 0; }
@@ -518,12 +535,12 @@ __device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lan
     for (int base = 0; base < len; base += 64) {
         int cnt = min(64, len - base);
         int i = len - 1 - base - lane;
-        uint2 e = make_uint2(0, 0);      // (observation, score bits)
-        if (lane < cnt) e = reinterpret_cast<const uint2*>(P.trace())[i];
+        uint4 e = make_uint4(0, 0, 0, 0);      // (-, observation, score bits, -)
+        if (lane < cnt) e = reinterpret_cast<const uint4*>(P.trace())[i];
         double x = 0;
         float xf = 0;
         for (int j = 0; j < cnt; ++j) {
-            float sj = rl_f32(__uint_as_float(e.y), j);   // wave-uniform source lane
+            float sj = rl_f32(__uint_as_float(e.z), j);   // wave-uniform source lane
             if (float_carry) {
                 Vf = Vf - sj;
                 if (lane == j) xf = Vf;
@@ -537,7 +554,7 @@ __device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lan
             }
         }
         if (lane < cnt) {
-            uint32_t* st = P.stat() + (size_t)e.x * 4;
+            uint32_t* st = P.stat() + (size_t)e.y * 4;
             if (float_carry) welford_f32carry(st, xf, varf);
             else welford_f64(st, x, var0);
         }
@@ -550,9 +567,9 @@ __device__ inline void lane_backup_trace_seq(const tm_store& S, const GP& P, int
     double V = v0;
     float Vf = (float)v0;
     for (int i = len - 1; i >= 0; --i) {
-        uint2 e = reinterpret_cast<const uint2*>(P.trace())[i];
-        float sj = __uint_as_float(e.y);
-        uint32_t* st = P.stat() + (size_t)e.x * 4;
+        uint4 e = reinterpret_cast<const uint4*>(P.trace())[i];
+        float sj = __uint_as_float(e.z);
+        uint32_t* st = P.stat() + (size_t)e.y * 4;
         if (float_carry) {
             Vf = Vf - sj;
             welford_f32carry(st, Vf, (float)var0);
@@ -573,9 +590,9 @@ __device__ inline bool trace_has_repeat(const GP& P, int lane, int len, const in
     bool rep = false;
     for (int base = 0; base < len; base += 64) {
         int i = base + lane;
-        uint32_t oi = (i < len) ? P.trace()[(size_t)i * 2] : 0xFFFFFFFFu;
+        uint32_t oi = (i < len) ? P.trace()[(size_t)i * 4 + 1] : 0xFFFFFFFFu;
         for (int j = 0; j < len; ++j) {
-            uint32_t oj = P.trace()[(size_t)j * 2];
+            uint32_t oj = P.trace()[(size_t)j * 4 + 1];
             if (i < len && j != i && oj == oi) rep = true;
         }
         for (int j = 0; j < n_extra; ++j)
@@ -708,7 +725,8 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
 template <bool VANILLA>
 __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, int g, int lane) {
     const long long tc_start = __builtin_readcyclecounter();
-    uint32_t rs = (lane < 32) ? S.rng[(size_t)g * 32 + lane] : 0u;   // glibc rand() state word i in lane i
+    if (lane < 32) L.misc[lane] = S.rng[(size_t)g * 32 + lane];      // glibc rand() state (31 words), used by check_low only
+    wave_sync();
     int rng_pos = P.gs()[TM_GS_RNG_POS];
     const int rng_pos0 = rng_pos;
     int idx = P.gs()[TM_GS_ROOT];
@@ -743,13 +761,13 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     const uint64_t lanes_lt56 = 0x00FFFFFFFFFFFFFFull;
     // trace: lane 56 (group 7 holds the node's own observation and score) appends 8 bytes per level; the other lanes
     // store theirs to a dummy slot, so the walk needs no exec masking for it
-    uint2* tp = (lane == 56) ? &L.tbuf[0] : &L.tdummy[lane];
+    uint4* tp = (lane == 56) ? &L.tbuf[0] : &L.tdummy[lane];
     const int tinc = (lane == 56) ? 1 : 0;
     int flushed = 0;
     auto flush_trace = [&](int upto) {   // entries [flushed, upto) from LDS to global, coalesced
         for (int base = flushed; base < upto; base += 64) {
             int i = base + lane;
-            if (i < upto) reinterpret_cast<uint2*>(P.trace())[i] = L.tbuf[i - flushed];
+            if (i < upto) reinterpret_cast<uint4*>(P.trace())[i] = L.tbuf[i - flushed];
         }
         flushed = upto;
     };
@@ -760,6 +778,10 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     int n_miss = 0;
 #ifdef TM_PROF_WALK
     long long prof_mem = 0;
+#define TM_WALK_PROF(SC, RN) { const long long tpa = __builtin_readcyclecounter(); asm volatile("" :: "v"(SC.x), "v"(RN.x)); \
+                               prof_mem += __builtin_readcyclecounter() - tpa; }
+#else
+#define TM_WALK_PROF(SC, RN)
 #endif
     // three record register sets and two statistics sets rotate through the roles (current node, predicted child,
     // predicted grandchild) / (this level, next level): the loop body is instantiated six times instead of moving
@@ -769,85 +791,78 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     uint4 s0 = buf_ld16(stat_rs, r0.y * 16u), s1 = s0;
     r1 = buf_ld16(rec_rs, p0 * (TM_REC_DW * 4u) + grp16);
     r2 = r1;
-    uint4 last = r0;         // the record of the node the walk ended at
-    bool done = false;
+    int cur_node = idx;
 #define TM_WALK_LEVEL(RC, PC, SC, RN, PN, SN, RNN)                                                                      \
-    if (!done) {                                                                                                        \
-        if ((len & (TRACE_LDS - 1)) == 0 && len != 0) {                                                                 \
-            if (len >= max_trace) { overflow = true; done = true; last = RC; }                                          \
-            else { wave_sync(); flush_trace(len); wave_sync(); if (lane == 56) tp = &L.tbuf[0]; }                       \
+    {                                                                                                                   \
+        if (__builtin_expect((len & (TRACE_LDS - 1)) == 0, 0)) {                                                        \
+            if (len != 0) {      /* the LDS trace buffer is full */                                                     \
+                if (len >= max_trace) { overflow = true; break; }                                                       \
+                wave_sync(); flush_trace(len); wave_sync();                                                             \
+                if (lane == 56) tp = &L.tbuf[0];                                                                        \
+            }                                                                                                           \
         }                                                                                                               \
-    }                                                                                                                   \
-    if (!done) {                                                                                                        \
-        *tp = make_uint2(RC.y, RC.z);                                                                                   \
+        *tp = RC;                /* lane 56 holds piece 7: (predicted child, own observation, own score, header) */     \
         tp += tinc;                                                                                                     \
         len += 1;                                                                                                       \
         const uint64_t onm = __builtin_amdgcn_ballot_w64(RC.x != 0u) & lanes_lt56;                                      \
-        if (onm == 0ull) { done = true; last = RC; }        /* no children: a leaf */                                   \
-        else {                                                                                                          \
-            TM_WALK_PROF(SC, RN)                                                                                        \
-            /* the next level's round of loads, on the assumption that the predicted child is the one */               \
+        if (onm == 0ull) break;                       /* no children: a leaf */                                         \
+        TM_WALK_PROF(SC, RN)                                                                                            \
+        /* the next level's round of loads, on the assumption that the predicted child is the one */                   \
+        PN = rl_u32(RN.x, 56);                                                                                          \
+        SN = buf_ld16(stat_rs, RN.y * 16u);                                                                             \
+        RNN = buf_ld16(rec_rs, PN * (TM_REC_DW * 4u) + grp16);                                                          \
+        __builtin_amdgcn_sched_barrier(0);        /* keep their issue ahead of the arithmetic below */                  \
+        const int visit = (int)(SC.x & vmask);                                                                          \
+        const uint64_t lowmask = __builtin_amdgcn_ballot_w64(visit < low) & onm;                                        \
+        uint64_t selmask;                         /* lanes of the selected group (at least its first) */                \
+        if (__builtin_expect(lowmask != 0ull, 0)) {                                                                     \
+            /* check_low (core.h:65-77): a uniformly drawn under-visited child, libc rand() */                          \
+            uint64_t mm = lowmask & 0x0101010101010101ull;      /* one bit per group */                                 \
+            const int m = __popcll(mm);                                                                                 \
+            const uint32_t r = wave_rand_lds(L.misc, rng_pos, lane);                                                    \
+            const int kth = (int)(r % (uint32_t)m);                                                                     \
+            for (int t = 0; t < kth; ++t) mm &= mm - 1;                                                                 \
+            selmask = mm;                                                                                               \
+        } else {                                                                                                        \
+            /* policy_clt (core.h:83-105): float arithmetic, one rounding per operation; the exploration term           \
+               sqrtf(variance / (float)visit) was evaluated (same two operations) when the statistics changed.          \
+               n = sum of the children's visits (empty slots read the null observation: 0 visits). */                   \
+            const int n = (int)group_sum_u32((uint32_t)visit);                                                          \
+            int cbits;                                                                                                  \
+            if (__builtin_expect(n >= nq_size, 0)) {                                                                    \
+                cbits = __builtin_amdgcn_readfirstlane(__float_as_int(norm_quantile_dev((double)n)));                   \
+                nq_fallback += 1;                                                                                       \
+            } else {                                                                                                    \
+                asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(cbits) : "s"(nq_base), "s"(n << 2)); \
+            }                                                                                                           \
+            const float t1 = __uint_as_float(SC.y) + __uint_as_float(RC.z);                                             \
+            const float val = t1 - __uint_as_float(RC.w);                                                               \
+            const float prod = __int_as_float(cbits) * __uint_as_float(SC.w);                                           \
+            const float q = (val + prod) + 0.0f;         /* -0 becomes +0 (the float compare treats them as equal) */   \
+            /* first-max argmax with the reference's scan semantics (max_q = q_0; i >= 1 replaces only if q_i > max_q): \
+               a NaN at i >= 1 never wins, a NaN at 0 is never replaced, ties keep the lower index.  Compared as        \
+               order-preserving integer keys. */                                                                        \
+            const uint32_t qb = __float_as_uint(q);                                                                     \
+            int key = (int)(qb ^ (((uint32_t)((int)qb >> 31)) >> 1));                                                   \
+            key = (q != q) ? nan_key : key;                                                                             \
+            key = (RC.x != 0u && lane < 56) ? key : (int)0x80000000;                                                    \
+            const int kmax = group_max_i32(key);                                                                        \
+            selmask = __builtin_amdgcn_ballot_w64(key == kmax);                                                         \
+        }                                                                                                               \
+        const uint32_t c = rl_u32(RC.x, __builtin_ctzll(selmask) & 56);                                                 \
+        if (__builtin_expect(c != PC, 0)) {                                                                             \
+            /* another child than the predicted one: remember it for the next walk through this node, fetch its         \
+               record, restart the pipeline */                                                                          \
+            if (lane == 56) P.rec()[(size_t)cur_node * TM_REC_DW + TM_REC_PCHILD] = c;                                  \
+            RN = buf_ld16(rec_rs, c * (TM_REC_DW * 4u) + grp16);                                                        \
             PN = rl_u32(RN.x, 56);                                                                                      \
             SN = buf_ld16(stat_rs, RN.y * 16u);                                                                         \
             RNN = buf_ld16(rec_rs, PN * (TM_REC_DW * 4u) + grp16);                                                      \
-            __builtin_amdgcn_sched_barrier(0);    /* keep their issue ahead of the arithmetic below */                  \
-            const int visit = (int)(SC.x & vmask);                                                                      \
-            const uint64_t lowmask = __builtin_amdgcn_ballot_w64(visit < low) & onm;                                    \
-            int sel;                                                                                                    \
-            if (lowmask) {                                                                                              \
-                /* check_low (core.h:65-77): a uniformly drawn under-visited child, libc rand() */                      \
-                uint64_t mm = lowmask & 0x0101010101010101ull;      /* one bit per group */                             \
-                const int m = __popcll(mm);                                                                             \
-                const uint32_t r = wave_rand(rs, rng_pos);                                                              \
-                const int kth = (int)(r % (uint32_t)m);                                                                 \
-                for (int t = 0; t < kth; ++t) mm &= mm - 1;                                                             \
-                sel = (__ffsll((long long)mm) - 1) >> 3;                                                                \
-            } else {                                                                                                    \
-                /* policy_clt (core.h:83-105): float arithmetic, one rounding per operation; the exploration term       \
-                   sqrtf(variance / (float)visit) was evaluated (same two operations) when the statistics changed.      \
-                   n = sum of the children's visits (empty slots read the null observation: 0 visits). */               \
-                const int n = (int)group_sum_u32((uint32_t)visit);                                                      \
-                float coeff;                                                                                            \
-                if (n < nq_size) {                                                                                      \
-                    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(coeff) : "s"(nq_base), "s"(n << 2)); \
-                } else { coeff = norm_quantile_dev((double)n); nq_fallback += 1; }                                      \
-                const float t1 = __uint_as_float(SC.y) + __uint_as_float(RC.z);                                         \
-                const float val = t1 - __uint_as_float(RC.w);                                                           \
-                const float prod = coeff * __uint_as_float(SC.w);                                                       \
-                const float q = (val + prod) + 0.0f;         /* -0 becomes +0 (the float compare treats them as equal) */ \
-                /* first-max argmax with the reference's scan semantics (max_q = q_0; i >= 1 replaces only if q_i >     \
-                   max_q): a NaN at i >= 1 never wins, a NaN at 0 is never replaced, ties keep the lower index.         \
-                   Compared as order-preserving integer keys. */                                                        \
-                const uint32_t qb = __float_as_uint(q);                                                                 \
-                int key = (int)(qb ^ (((uint32_t)((int)qb >> 31)) >> 1));                                               \
-                key = (q != q) ? nan_key : key;                                                                         \
-                key = (RC.x != 0u && lane < 56) ? key : (int)0x80000000;                                                \
-                const int kmax = group_max_i32(key);                                                                    \
-                sel = (__ffsll((long long)__builtin_amdgcn_ballot_w64(key == kmax)) - 1) >> 3;                          \
-            }                                                                                                           \
-            const uint32_t c = rl_u32(RC.x, sel * 8);                                                                   \
-            idx = (int)c;                                                                                               \
-            if (c != PC) {                                                                                              \
-                /* another child than the predicted one: remember it for the next walk through this node, fetch its     \
-                   record, restart the pipeline */                                                                      \
-                if (lane == 56) P.rec()[(size_t)cur_node * TM_REC_DW + TM_REC_PCHILD] = c;                              \
-                RN = buf_ld16(rec_rs, c * (TM_REC_DW * 4u) + grp16);                                                    \
-                PN = rl_u32(RN.x, 56);                                                                                  \
-                SN = buf_ld16(stat_rs, RN.y * 16u);                                                                     \
-                RNN = buf_ld16(rec_rs, PN * (TM_REC_DW * 4u) + grp16);                                                  \
-                n_miss += 1;                                                                                            \
-            }                                                                                                           \
-            cur_node = idx;                                                                                             \
+            n_miss += 1;                                                                                                \
         }                                                                                                               \
+        cur_node = (int)c;                                                                                              \
     }
-#ifdef TM_PROF_WALK
-#define TM_WALK_PROF(SC, RN) { const long long tpa = __builtin_readcyclecounter(); asm volatile("" :: "v"(SC.x), "v"(RN.x)); \
-                               prof_mem += __builtin_readcyclecounter() - tpa; }
-#else
-#define TM_WALK_PROF(SC, RN)
-#endif
-    int cur_node = idx;
-    while (!done) {
+    for (;;) {
         TM_WALK_LEVEL(r0, p0, s0, r1, p1, s1, r2)
         TM_WALK_LEVEL(r1, p1, s1, r2, p2, s0, r0)
         TM_WALK_LEVEL(r2, p2, s0, r0, p0, s1, r1)
@@ -858,10 +873,14 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
 #undef TM_WALK_LEVEL
 #undef TM_WALK_PROF
     idx = cur_node;
-    const uint4 cur = last;
-    hdr = rl_u32(cur.w, 56);
-    self_o = rl_u32(cur.y, 56);
-    const uint32_t self_sc = rl_u32(cur.z, 56);
+    wave_sync();
+    // piece 7 of the node the walk ended at = the last trace entry (on a trace overflow the node is not recorded: it is
+    // treated as terminal and none of these is used)
+    const uint4 cur = L.tbuf[(len - 1 - flushed) & (TRACE_LDS - 1)];
+    const uint32_t rng_keep = (lane < 32) ? L.misc[lane] : 0u;     // L.misc is reused by the expansion
+    hdr = cur.w;
+    self_o = cur.y;
+    const uint32_t self_sc = cur.z;
     wave_sync();
     flush_trace(len);
     const long long tc_sel = __builtin_readcyclecounter();
@@ -909,7 +928,7 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
 #endif
     }
     if (rng_pos != rng_pos0) {
-        if (lane < 32) S.rng[(size_t)g * 32 + lane] = rs;
+        if (lane < 32) S.rng[(size_t)g * 32 + lane] = rng_keep;
         if (lane == 0) P.gs()[TM_GS_RNG_POS] = rng_pos;
     }
     wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end | (overflow ? 1 : 0), self_o, self_sc);

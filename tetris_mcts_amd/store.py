@@ -68,7 +68,7 @@ class TreeStore:
             node_rec=z(G, N, 32), node_child=z(G, N, 8), node_game=z(G, N, 16), obs_stat=z(G, N, 4), obs_key=z(G, N, 12),
             node_tab=z(G, cap, dtype=torch.int64), obs_tab=z(G, cap, dtype=torch.int64),
             free_node=z(G, N), free_obs=z(G, N), gs=z(G, 64), rng=z(G, 32), env_game=z(G, 16), env_line_stats=z(G, 4),
-            trace=z(G, max_trace, 2), leaf=z(G, 32), eval_obs=z(G * eval_slots),
+            trace=z(G, max_trace, 4), leaf=z(G, 32), eval_obs=z(G * eval_slots),
             eval_v=z(G * eval_slots, dtype=torch.float32), eval_var=z(G * eval_slots, dtype=torch.float32),
             gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N),
             replay_obs=z(G, max(replay_cap, 1), 12), replay_stat=z(G, max(replay_cap, 1), 4, dtype=torch.float32),
