@@ -32,9 +32,9 @@ env_args = ((20, 10), 1, 0, 0)
 game = Tetris(*env_args, seed=1234, n_games=G)
 model = M.Model_VV(backend="hip", seed=0)
 agent = getattr(agents, args.agent)(sims=args.sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=args.max_nodes,
-                                    model=model, online=True, replay_cap=8192)
+                                    model=model, online=True, replay_cap=16384)
 agent.update_root(game)
-t0 = time.time()
+t0 = t_round = time.time()
 moves, rounds = 0, 0
 ep_lines, ep_scores, ep_len = [], [], []
 alive = np.zeros(G, np.int64)
@@ -65,7 +65,11 @@ while time.time() - t0 < args.minutes * 60:
                    mean_episode_moves=float(np.mean(ep_len)) if ep_len else None,
                    new_tuples=tuples, trained=res is not None, train_iters=(res or {}).get("iters"),
                    best_val=(res or {}).get("best_validation"), train_s=round(time.time() - tt, 1),
-                   gcs=agent.store.counter("N_GC"))
+                   gcs=agent.store.counter("N_GC"), gc_slices=agent.store.counter("GC_SLICES"),
+                   dropped_tuples=agent.store.counter("N_DROPPED"), pool_resets=agent.store.counter("N_POOL_RESET"),
+                   catchup_launches=int((agent.store.search_stats(agent.n_sub, agent.ev_every, reset=False) or {}).get("catchup_launches", 0)),
+                   round_s=round(time.time() - t_round, 1))
+        t_round = time.time()
         log.write(json.dumps(rec) + "\n")
         log.flush()
         print(rec, flush=True)

@@ -75,6 +75,13 @@ class ValueSim(TreeAgent):
         s = self.store
         keys, stats = s.replay()
         s.t["replay_count"].zero_()
+        dropped = s.counter("N_DROPPED")
+        if dropped > getattr(self, "_dropped_seen", 0):
+            # the reference keeps every qualifying observation up to memory_size (ValueSim.py:122-159): say so when the
+            # device-side harvest buffer was too small between two drains
+            print("WARNING: {} harvested tuples did not fit the device replay buffer (replay_cap={}); drain more often or "
+                  "raise replay_cap".format(dropped - getattr(self, "_dropped_seen", 0), s.s.replay_cap), file=stderr, flush=True)
+            self._dropped_seen = dropped
         if self._memory is not None:
             keys = torch.cat([self._memory[0], keys])
             stats = torch.cat([self._memory[1], stats])
