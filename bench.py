@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--split", type=int, default=int(os.environ.get("TM_BENCH_SPLIT", "1")),
                     help="sub-batches of the rank's games on separate HIP streams (one sub-batch's tree kernel runs "
                     "under another's value-net kernels)")
-    ap.add_argument("--gc-slice-cycles", type=int, default=150000)
+    ap.add_argument("--gc-slice-cycles", type=int, default=250000)
     ap.add_argument("--online", action="store_true", help="harvest training tuples at GC and all-gather them every move")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -119,8 +119,7 @@ def main():
 
     def one_step(timed):
         nonlocal episodes, lines
-        agent.mcts(sims)
-        _, action = S.root_stats()
+        action = agent.play()      # mcts(sims) + get_action (games whose reachable tree outgrew the pool restart with an empty tree)
         game.play(action)
         agent.update_root(game)   # reads game.end: one small host sync per move, as the reference's loop has
         ended = np.atleast_1d(game.end)
@@ -152,7 +151,7 @@ def main():
                 gather["checksum_ok"] &= bool(int(tot[1].item()) == int(ka.shape[0]) and int(tot[0].item()) == int(got.item()))
 
     def counters():
-        return {k: S.counter(k) for k in ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL", "N_GC", "GC_SLICES", "N_DROPPED")}
+        return {k: S.counter(k) for k in ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL", "N_GC", "GC_SLICES", "N_DROPPED", "N_POOL_RESET")}
 
     for _ in range(args.warmup):
         one_step(False)
@@ -175,14 +174,14 @@ def main():
     max_trace = int(S.t["gs"][:, st.GS["MAX_TRACE"]].max().item())
     d = {k: c1[k] - c0[k] for k in c0}
     tot = torch.tensor([elapsed, d["N_EXPAND"], d["N_SIMS"], d["TRACE_SUM"], d["N_EVAL"], episodes, lines, err,
-                        d["N_GC"], d["GC_SLICES"], d["N_DROPPED"], ss.get("catchup_launches", 0.0)],
+                        d["N_GC"], d["GC_SLICES"], d["N_DROPPED"], ss.get("catchup_launches", 0.0), d["N_POOL_RESET"]],
                        dtype=torch.float64, device=dev)
     if world > 1:
         tmax = tot[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         tot[0] = tmax[0]
-    elapsed, n_exp, n_sims, tr_sum, n_eval, episodes, lines, err, n_gc, gc_slices, dropped, catchup = [float(x) for x in tot.cpu()]
+    elapsed, n_exp, n_sims, tr_sum, n_eval, episodes, lines, err, n_gc, gc_slices, dropped, catchup, pool_resets = [float(x) for x in tot.cpu()]
 
     if rank != 0:
         if world > 1:
@@ -222,7 +221,7 @@ def main():
         "error_games": int(err),
         "walk_mispredicted_levels": S.counter("N_WALK_MISS") / max(S.counter("TRACE_SUM"), 1),
         "gc": {"collections": int(n_gc), "slices": int(gc_slices), "catchup_launches": int(catchup),
-               "dropped_tuples": int(dropped)},
+               "dropped_tuples": int(dropped), "trees_restarted_pool_outgrown": int(pool_resets)},
         "store_gib_per_gpu": S.nbytes() / 2**30,
         "last_sim_phase_kcycles": {k: float(S.t["gs"][:, st.GS[k]].float().mean().item()) / 1e3
                                    for k in ("CYC_BACK", "CYC_SELECT", "CYC_EXPAND", "CYC_WALK_MEM", "TRACE_LEN")},
@@ -379,7 +378,24 @@ def cpu_baseline(args, model):
     sources are (DESIGN.md section 5 lists that number).  Fallback kind "port": the oracle's C restatement."""
     sd = {k: v.detach().cpu() for k, v in model.model.state_dict().items()}
     ncpu = os.cpu_count() or 1
-    nproc = args.cpu_procs or min(ncpu, 128)
+    quota = None        # a container may own fewer cores than it sees (cgroup v2 cpu.max / v1 cfs quota)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except Exception:
+            quota = None
+    try:
+        ncpu_aff = len(os.sched_getaffinity(0))
+    except Exception:
+        ncpu_aff = ncpu
+    usable = int(min(ncpu_aff, quota) if quota else ncpu_aff)
+    nproc = args.cpu_procs or max(1, min(usable, 128))
     sample = "1 game per process x %d sims/move from a fresh game (seed 20260925+i), pool %d, same network weights, %.0f s per process"
     kind = "reference"
     one, errs = _cpu_run(kind, 1, args, sd, args.cpu_seconds)
@@ -393,7 +409,7 @@ def cpu_baseline(args, model):
            "sample": (sample % (args.sims, args.max_nodes, args.cpu_seconds)) +
                      ("; the reference's compiled MCTSAgent (agent.cpp, LP=%s) + torch CPU Net, 1 thread per process" % (args.agent != "ValueSim")
                       if kind == "reference" else "; oracle C restatement incl. its fp32 value net"),
-           "host_cpus": ncpu,
+           "host_cpus": ncpu, "cpu_affinity": ncpu_aff, "cgroup_cpu_quota": quota,
            "one_core": {"value": one["value"], "sims_per_sec": one["sims_per_sec"], "moves": one["moves"]},
            "all_cores": None if many is None else {"value": many["value"], "procs": many["procs_ok"], "sims_per_sec": many["sims_per_sec"],
                                                    "per_core": many["value"] / max(many["procs_ok"], 1), "wall_s": many["wall"]}}

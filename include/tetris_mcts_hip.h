@@ -61,7 +61,8 @@ enum {
        while started < target, so games that lost launches to a collection catch up in extra launches (tm_sims_remaining) */
     TM_GS_SIM_TARGET = 40, TM_GS_SIM_STARTED,
     TM_GS_CYC_WALK_MEM,  /* profiling builds (-DTM_PROF_WALK): cycles of the last walk spent waiting for its loads */
-    TM_GS_N_WALK_MISS    /* tree levels at which the walk descended into another child than the predicted one (all simulations) */
+    TM_GS_N_WALK_MISS,   /* tree levels at which the walk descended into another child than the predicted one (all simulations) */
+    TM_GS_POOL_FULL      /* the reachable tree fills the pool (TM_ERR_POOL): no collection is attempted until the root moves */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
@@ -150,6 +151,7 @@ int tm_move_begin(const tm_store *s, int sims, void *stream);
 int tm_sims_remaining(const tm_store *s, int32_t *out /* device int: max over games of launches still needed */, void *stream);
 #define TM_SIM_BACKUP 1  /* finish the pending simulation: backup with eval_v/eval_var */
 #define TM_SIM_FRONT 2   /* start one: select, expand, post evaluation requests into eval_obs */
+#define TM_SIM_GC_FULL 4 /* a game that is collecting garbage finishes the collection in this launch (catch-up launches) */
 int tm_sim_step(const tm_store *s, int flags, void *stream);
 int tm_eval_render(const tm_store *s, int8_t *out /* [G*eval_slots][200] */, void *stream);
 

@@ -145,10 +145,10 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
         TM_TRY(hipEventRecord(h->ev_start, caller));
         for (int k = 0; k < K; ++k) TM_TRY(hipStreamWaitEvent(st[k], h->ev_start, 0));
     }
-    auto step = [&](int k) -> int {
+    auto step = [&](int k, int extra = 0) -> int {
         if (h->sub[k].n_games == 0) return 0;
         h->launches += 1;
-        return tm_sim_step(&h->sub[k], TM_SIM_BACKUP | TM_SIM_FRONT, st[k]);
+        return tm_sim_step(&h->sub[k], TM_SIM_BACKUP | TM_SIM_FRONT | extra, st[k]);
     };
     auto nn = [&](int k) -> int {
         if (!vn_params || h->sub[k].n_games == 0) return 0;
@@ -193,7 +193,7 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
             for (int k = 0; k < K; ++k)
                 if (h->rem_host[k] > i) {
                     TM_TRY(nn(k));
-                    TM_TRY(step(k));
+                    TM_TRY(step(k, TM_SIM_GC_FULL));      // only laggards are left: a collection in progress runs to its end
                     h->extra_launches += 1;
                 }
     }

@@ -408,14 +408,17 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
             int i1, o1;
             wave_new_nodes(S, P, L, g, 1, lane, i1, o1);
             if (i1 < 0) {
-                if (!P.gs()[TM_GS_GC_RETRY]) {
+                if (!P.gs()[TM_GS_GC_RETRY] && !P.gs()[TM_GS_POOL_FULL]) {
                     if (lane < GAME_DW) L.slots[0][lane] = keep;
                     if (lane == 0) { P.gs()[TM_GS_GC_PHASE] = 1; P.gs()[TM_GS_GC_RETRY] = 1; }
                     wave_sync();
                     return false;
                 }
-                // the pool is exhausted although everything unreachable has just been reclaimed
-                if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_POOL);
+                // The pool is exhausted although everything unreachable has just been reclaimed: the reachable tree has
+                // outgrown it (the reference prints MAX_NODES EXCEEDED and runs into undefined behaviour, agent.cpp:227-231).
+                // Nothing becomes unreachable before the root moves, so no further collection is attempted until then
+                // (TM_GS_POOL_FULL; without it every remaining simulation of the move would sweep the whole pool in vain).
+                if (lane == 0) { atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_POOL); P.gs()[TM_GS_POOL_FULL] = 1; }
                 i1 = 0; o1 = 0;
             }
             i1 = (int)rl_u32((uint32_t)i1, 0);
@@ -1212,7 +1215,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     int32_t* gs = P.gs();
     if (gs[TM_GS_GC_PHASE] != 0) {
         // this game is collecting garbage: one slice per launch (S.gc_slice_cycles; 0 = to completion), no simulation
-        if (!gc_run(S, P, g, lane, S.gc_slice_cycles > 0 ? (long long)S.gc_slice_cycles : -1)) return;
+        // (catch-up launches pass TM_SIM_GC_FULL: only laggards are left, nobody is held up by a collection run to its end)
+        const bool sliced = S.gc_slice_cycles > 0 && !(flags & TM_SIM_GC_FULL);
+        if (!gc_run(S, P, g, lane, sliced ? (long long)S.gc_slice_cycles : -1)) return;
     }
     const int pend = gs[TM_GS_PENDING];
     if (pend == 2) {
@@ -1223,6 +1228,17 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc);
         return;
     }
+#ifndef TM_NO_SETPRIO
+    // A launch lasts as long as its slowest wave, and a wave's time is proportional to the length of its game's walk (mean
+    // 69 nodes, maximum 160 at 4096 games).  The games with the longest walks get issue priority over the three other
+    // waves of their SIMD (static priority: the loser pays little, it was going to wait for this wave anyway).
+    {
+        const int last_len = gs[TM_GS_TRACE_LEN];
+        if (last_len >= 112) __builtin_amdgcn_s_setprio(3);
+        else if (last_len >= 88) __builtin_amdgcn_s_setprio(2);
+        else if (last_len >= 72) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     const long long t0 = __builtin_readcyclecounter();
     if ((flags & TM_SIM_BACKUP) && pend == 1) {
         wave_sim_back(S, P, L, lane);
@@ -1275,6 +1291,7 @@ __global__ __launch_bounds__(64 * WPB) void k_update_root(tm_store S) {
     }
     if (lane == 0) {
         P.gs()[TM_GS_ROOT] = idx;
+        P.gs()[TM_GS_POOL_FULL] = 0;        // a new root: the old root's siblings are garbage now
         if ((L.slots[0][11] >> 8) & 1u) P.gs()[TM_GS_EPISODE] += 1;
     }
 }
@@ -1359,6 +1376,7 @@ __global__ void k_pool_reset(tm_store S, const uint8_t* mask) {
         P.gs()[TM_GS_PENDING] = 0;
         P.gs()[TM_GS_GC_PHASE] = 0;
         P.gs()[TM_GS_GC_RETRY] = 0;
+        P.gs()[TM_GS_POOL_FULL] = 0;
         P.gs()[TM_GS_GC_CYC16] = 0;
         P.gs()[TM_GS_SIM_STARTED] = P.gs()[TM_GS_SIM_TARGET];
         P.gs()[TM_GS_ERR] &= ~TM_ERR_POOL;

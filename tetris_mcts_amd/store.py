@@ -10,12 +10,12 @@ import torch
 
 from . import _lib
 
-SIM_BACKUP, SIM_FRONT = 1, 2
+SIM_BACKUP, SIM_FRONT, SIM_GC_FULL = 1, 2, 4
 KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA, KIND_VANILLA_C = 0, 1, 2, 3, 4, 5
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18, MAX_TRACE=19, N_DROPPED=25,
           CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_SLICES=38,
-          SIM_TARGET=40, SIM_STARTED=41, CYC_WALK_MEM=42, N_WALK_MISS=43)
+          SIM_TARGET=40, SIM_STARTED=41, CYC_WALK_MEM=42, N_WALK_MISS=43, POOL_FULL=44)
 
 _nq_cache = {}
 
@@ -44,7 +44,7 @@ class TreeStore:
 
     def __init__(self, n_games, max_nodes=100000, kind=KIND_VALUESIM, env_args=((20, 10), 1, 0, 0), gamma=0.999,
                  low=1, eval_slots=None, max_trace=1024, nq_size=1 << 20, online=False, min_visits_to_store=10,
-                 replay_cap=0, gc_slice_cycles=150000, device="cuda"):
+                 replay_cap=0, gc_slice_cycles=250000, device="cuda"):
         if not torch.cuda.is_available():
             raise RuntimeError("tetris_mcts_amd needs a ROCm GPU (gfx950); there is no CPU path")
         shape, app, scoring, randomizer = env_args[0], env_args[1], env_args[2], env_args[3]
