@@ -198,6 +198,16 @@ int tm_core_get_unique_child_obs(int n_trees, int n_nodes, const int32_t *index,
 int tm_core_get_all_childs(int n_trees, int n_nodes, const int32_t *roots, const int32_t *child,
                            uint8_t *mark /* [B][n_nodes] */, int32_t *queue /* [B][n_nodes] scratch */, void *stream);
 
+/* distributional head helpers (agents/cppmodule/core.h:387-449; defined there, not exported by core.cpp): n categorical
+ * distributions of `bins` atoms over [vmin, vmax).  tm_dist_transform: every source bin is an interval `scale` bins wide
+ * shifted by shift[i] (in value units), its mass split over the two destination bins it overlaps (mass beyond the last
+ * bin is dropped - the reference writes one float past its vector there).  tm_dist_mean_variance: out[i] = (mean, variance)
+ * in double, bin centres vmin + (b + 1/2) delta accumulated as the reference does. */
+int tm_dist_transform(int n, int bins, const float *dist /* [n][bins] */, double vmin, double vmax,
+                      const double *shift /* [n] */, double scale, float *out /* [n][bins] */, void *stream);
+int tm_dist_mean_variance(int n, int bins, const float *dist, double vmin, double vmax, double *out /* [n][2] */,
+                          void *stream);
+
 /* value network forward (model/model_vv.py:13-52; Model_VV.inference 210-217): states int8 [n][200] -> v[n], var[n].
  * params: 478342 floats in PyTorch state_dict layouts (order as in oracle/valuenet_oracle.c).
  * tm_valuenet_prepare re-lays the conv2/conv3/fc1 weights into MFMA operand streams (call after every weight

@@ -85,6 +85,9 @@ def lib():
         L.orc_get_all_childs.argtypes = [i32, vp, i32, vp]
         L.orc_valuenet_forward.argtypes = [vp, vp, i32, vp, vp]
         L.orc_hash_eval.argtypes = [vp, vp, i32, vp, vp]
+        L.orc_transform_distribution.argtypes = [vp, i32, f64, f64, f64, f64, vp]
+        L.orc_mean_dist.restype, L.orc_mean_dist.argtypes = f64, [vp, i32, f64, f64]
+        L.orc_mean_variance_dist.argtypes = [vp, i32, f64, f64, vp]
         _lib = L
     return _lib
 

@@ -466,6 +466,34 @@ def gen_vanillac():
         json.dump(out, f)
 
 
+def gen_dist():
+    """ref_dist.npz: the reference's distribution helpers (core.h:387-449, compiled through oracle/ref_dist_shim.cpp) on
+    seeded categorical distributions.  Only cases in which the reference's write to result[bins] adds exactly 0 or does not
+    happen (it is a heap overrun otherwise - `python -c` with shift 3.0 aborts with "corrupted size vs. prev_size")."""
+    B.build(ref=True)
+    m = B.load_ref_native("dist")
+    rng = np.random.default_rng(77)
+    cases = []
+    for bins in (50, 50, 32, 64):
+        for vmin, vmax in ((0.0, 100.0), (-20.0, 380.0)):
+            for shift, scale in ((0.0, 1.0), (-7.3, 1.0), (-30.0, 0.99), (-0.5, 0.9), (-55.0, 0.999), (0.0, 0.95)):
+                d = rng.random(bins).astype(np.float32)
+                d[rng.random(bins) < 0.2] = 0
+                d /= d.sum()
+                delta = (vmax - vmin) / bins
+                lb = np.maximum(np.arange(bins) * scale + shift / delta, 0.0)
+                ub = np.minimum(lb + scale, float(bins))
+                frac = np.floor(ub) - lb
+                assert ((np.floor(ub) < bins) | (frac == 1.0)).all()      # no harmful overrun in the reference
+                out = np.asarray(m.transform_distribution(d, vmin, vmax, shift, scale), np.float32)
+                mv = m.mean_variance_dist(d, vmin, vmax)
+                cases.append(dict(dist=d, vmin=vmin, vmax=vmax, shift=shift, scale=scale, out=out,
+                                  mean=m.mean_dist(d, vmin, vmax), mv=np.asarray(mv, np.float64)))
+    np.savez_compressed(os.path.join(OUT, "ref_dist.npz"), n=len(cases),
+                        **{"%s_%d" % (k, i): np.asarray(c[k]) for i, c in enumerate(cases) for k in c})
+    print("ref_dist.npz:", len(cases), "cases")
+
+
 def _legacy_torch_overloads():
     """model/yogi.py and model/model_vv.py call `add(number, tensor)`, `add_(number, tensor)`, `addcmul_(number, t, t)` and
     `addcdiv_(number, t, t)`, signatures PyTorch removed after 1.x.  Re-add them (number first = `alpha` / `value`) so the
@@ -565,7 +593,7 @@ def gen_training():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training", "vanillac"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training", "vanillac", "dist"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -587,6 +615,8 @@ if __name__ == "__main__":
         gen_training()
     if "vanillac" in which:
         gen_vanillac()
+    if "dist" in which:
+        gen_dist()
     if "agents" in which:
         if params is None:
             params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]

@@ -164,3 +164,26 @@ def test_core_api_mixture_backup(golden_dir):
         assert t_visit.cpu().numpy()[:no].tobytes() == gold["m%d_visit1" % ci].tobytes(), ci
         assert t_value.cpu().numpy()[:no].tobytes() == gold["m%d_value1" % ci].tobytes(), ci
         assert t_var.cpu().numpy()[:no].tobytes() == gold["m%d_variance1" % ci].tobytes(), ci
+
+
+def test_distribution_helpers_match_the_reference(golden_dir):
+    """tm_dist_transform / tm_dist_mean_variance vs the reference's own core.h:387-449 outputs (ref_dist.npz), batched."""
+    import torch
+    from tetris_mcts_amd import _lib
+    from tetris_mcts_amd.store import _p, _stream
+    g = np.load(os.path.join(golden_dir, "ref_dist.npz"))
+    L = _lib.lib()
+    by_cfg = {}
+    for i in range(int(g["n"])):
+        key = (len(g["dist_%d" % i]), float(g["vmin_%d" % i]), float(g["vmax_%d" % i]), float(g["scale_%d" % i]))
+        by_cfg.setdefault(key, []).append(i)
+    for (bins, vmin, vmax, scale), idx in by_cfg.items():
+        d = torch.from_numpy(np.stack([g["dist_%d" % i] for i in idx]).astype(np.float32)).cuda()
+        sh = torch.from_numpy(np.array([float(g["shift_%d" % i]) for i in idx], np.float64)).cuda()
+        out = torch.zeros_like(d)
+        mv = torch.zeros(len(idx), 2, dtype=torch.float64, device="cuda")
+        _lib.check(L.tm_dist_transform(len(idx), bins, _p(d), vmin, vmax, _p(sh), scale, _p(out), _stream()), "tm_dist_transform")
+        _lib.check(L.tm_dist_mean_variance(len(idx), bins, _p(d), vmin, vmax, _p(mv), _stream()), "tm_dist_mean_variance")
+        for j, i in enumerate(idx):
+            assert out[j].cpu().numpy().tobytes() == g["out_%d" % i].astype(np.float32).tobytes(), i
+            assert mv[j].cpu().numpy().tobytes() == g["mv_%d" % i].astype(np.float64).tobytes(), i

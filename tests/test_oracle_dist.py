@@ -1,0 +1,38 @@
+"""The distribution helpers of the reference (agents/cppmodule/core.h:387-449, BASELINE configs[4]'s pinnable part):
+oracle/dist_oracle.c against the reference's own outputs (tests/golden/ref_dist.npz, make_golden.py gen_dist)."""
+import os
+
+import numpy as np
+
+
+def _cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ref_dist.npz"))
+    for i in range(int(g["n"])):
+        yield {k: g["%s_%d" % (k, i)] for k in ("dist", "vmin", "vmax", "shift", "scale", "out", "mean", "mv")}
+
+
+def test_dist_oracle_matches_reference_bit_for_bit(oracle, golden_dir):
+    L = oracle.lib()
+    n = 0
+    for c in _cases(golden_dir):
+        d = np.ascontiguousarray(c["dist"], np.float32)
+        bins = len(d)
+        out = np.zeros(bins, np.float32)
+        L.orc_transform_distribution(oracle.ptr(d), bins, float(c["vmin"]), float(c["vmax"]), float(c["shift"]), float(c["scale"]),
+                                     oracle.ptr(out))
+        assert out.tobytes() == c["out"].astype(np.float32).tobytes(), n
+        assert L.orc_mean_dist(oracle.ptr(d), bins, float(c["vmin"]), float(c["vmax"])) == float(c["mean"])
+        mv = np.zeros(2, np.float64)
+        L.orc_mean_variance_dist(oracle.ptr(d), bins, float(c["vmin"]), float(c["vmax"]), oracle.ptr(mv))
+        assert mv.tobytes() == c["mv"].astype(np.float64).tobytes(), n
+        n += 1
+    assert n == 48
+
+
+def test_transform_distribution_drops_the_mass_beyond_the_top(oracle):
+    """Where the reference writes result[bins] (one past its vector) the restatement drops that mass."""
+    L = oracle.lib()
+    d = np.full(50, 0.02, np.float32)
+    out = np.zeros(50, np.float32)
+    L.orc_transform_distribution(oracle.ptr(d), 50, 0.0, 100.0, 3.0, 0.99, oracle.ptr(out))
+    assert 0.9 < out.sum() < 1.0 and out[0] == 0.0 and out[1] > 0

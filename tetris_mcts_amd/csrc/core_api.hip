@@ -227,6 +227,48 @@ __global__ void k_all_childs(int B, int N, const int32_t* roots, const int32_t* 
 using namespace tmcts_core;
 #define GRID(B) dim3(((B) + 63) / 64), dim3(64), 0, (hipStream_t)stream
 
+// ---------------------------------------------------------------------------------------------------
+// The reference's distribution helpers (agents/cppmodule/core.h:387-449: transform_distribution, mean_variance_dist /
+// mean_dist; BASELINE configs[4]), one lane per distribution, bins in the reference's order so float / double roundings
+// are the reference's.  Mass that falls beyond the last bin is dropped (the reference writes result[bins] there, one
+// float past its vector).
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_dist_transform(int n, int bins, const float* __restrict__ dist, double vmin, double vmax,
+                                 const double* __restrict__ shift, double scale, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* d = dist + (size_t)i * bins;
+    float* r = out + (size_t)i * bins;
+    for (int b = 0; b < bins; ++b) r[b] = 0.0f;
+    const double delta = (vmax - vmin) / bins;
+    const double bin_shift = shift[i] / delta;
+    for (int b = 0; b < bins; ++b) {
+        const double lb = fmax(b * scale + bin_shift, 0.);
+        const int b_lb = (int)floor(lb);
+        const double ub = fmin(lb + scale, (double)bins);
+        const int b_ub = (int)floor(ub);
+        const double frac = b_ub - lb;
+        if (b_lb < bins) r[b_lb] = (float)((double)r[b_lb] + (double)d[b] * frac);
+        if (b_ub < bins) r[b_ub] = (float)((double)r[b_ub] + (double)d[b] * (1 - frac));
+    }
+}
+__global__ void k_dist_mean_variance(int n, int bins, const float* __restrict__ dist, double vmin, double vmax,
+                                     double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* d = dist + (size_t)i * bins;
+    const double delta = (vmax - vmin) / bins;
+    double mean = 0, m2 = 0, center = vmin + 0.5 * delta;
+    for (int b = 0; b < bins; ++b) {
+        const double tmp = center * d[b];
+        mean += tmp;
+        m2 += center * tmp;
+        center += delta;
+    }
+    out[2 * i] = mean;
+    out[2 * i + 1] = m2 - mean * mean;
+}
+
 extern "C" {
 int tm_core_select_trace_obs(int B, int N, const int32_t* roots, const int32_t* child, const int32_t* visit,
                              const float* value, const float* variance, const float* score, const int32_t* n_to_o,
@@ -260,6 +302,19 @@ int tm_core_get_unique_child_obs(int B, int N, const int32_t* index, const int32
 int tm_core_get_all_childs(int B, int N, const int32_t* roots, const int32_t* child, uint8_t* mark, int32_t* queue,
                            void* stream) {
     hipLaunchKernelGGL(k_all_childs, GRID(B), B, N, roots, child, mark, queue);
+    return (int)hipGetLastError();
+}
+int tm_dist_transform(int n, int bins, const float* dist, double vmin, double vmax, const double* shift, double scale,
+                      float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_dist_transform, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, bins, dist, vmin, vmax,
+                       shift, scale, out);
+    return (int)hipGetLastError();
+}
+int tm_dist_mean_variance(int n, int bins, const float* dist, double vmin, double vmax, double* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_dist_mean_variance, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, bins, dist, vmin,
+                       vmax, out);
     return (int)hipGetLastError();
 }
 }
