@@ -494,6 +494,30 @@ def gen_dist():
     print("ref_dist.npz:", len(cases), "cases")
 
 
+def gen_distnet():
+    """ref_distnet.npz: the reference's distributional `Net` (model/model_distributional.py:18-57) on CPU fp32 under
+    manual_seed(0): its state_dict, 16 inputs [16,1,22,10] in {-1,0,1}, softmax outputs and log_prob."""
+    ref_shims.install()
+    _legacy_torch_overloads()
+    import torch
+    torch.set_num_threads(1)
+    from model.model_distributional import Net
+    torch.manual_seed(0)
+    net = Net(atoms=50).eval()
+    rng = np.random.default_rng(3)
+    x = np.zeros((16, 1, 22, 10), np.float32)
+    for i in range(16):
+        h = int(rng.integers(0, 16))
+        x[i, 0, 22 - h:, :] = (rng.random((h, 10)) < 0.7)
+        x[i, 0, 3:5, 4:6] = -1
+    with torch.no_grad():
+        y = net(torch.from_numpy(x)).numpy()
+        lp = net.log_prob(torch.from_numpy(x)).numpy()
+    sd = {k.replace(".", "__"): v.numpy() for k, v in net.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "ref_distnet.npz"), x=x, y=y, lp=lp, **sd)
+    print("ref_distnet.npz: y sums", y.sum(1)[:3], "keys", sorted(sd))
+
+
 def _legacy_torch_overloads():
     """model/yogi.py and model/model_vv.py call `add(number, tensor)`, `add_(number, tensor)`, `addcmul_(number, t, t)` and
     `addcdiv_(number, t, t)`, signatures PyTorch removed after 1.x.  Re-add them (number first = `alpha` / `value`) so the
@@ -593,7 +617,7 @@ def gen_training():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training", "vanillac", "dist"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training", "vanillac", "dist", "distnet"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -617,6 +641,8 @@ if __name__ == "__main__":
         gen_vanillac()
     if "dist" in which:
         gen_dist()
+    if "distnet" in which:
+        gen_distnet()
     if "agents" in which:
         if params is None:
             params = np.load(os.path.join(OUT, "ref_valuenet.npz"))["params"]

@@ -36,3 +36,21 @@ def test_transform_distribution_drops_the_mass_beyond_the_top(oracle):
     out = np.zeros(50, np.float32)
     L.orc_transform_distribution(oracle.ptr(d), 50, 0.0, 100.0, 3.0, 0.99, oracle.ptr(out))
     assert 0.9 < out.sum() < 1.0 and out[0] == 0.0 and out[1] > 0
+
+
+def test_distributional_net_matches_the_reference(golden_dir):
+    """tetris_mcts_amd.model_distributional.Net loads the reference Net's state_dict as is and reproduces its outputs
+    (CPU, same torch ops: bit for bit)."""
+    import torch
+    from tetris_mcts_amd.model_distributional import Net
+    g = np.load(os.path.join(golden_dir, "ref_distnet.npz"))
+    net = Net(atoms=50).eval()
+    sd = {k.replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k not in ("x", "y", "lp")}
+    assert sorted(sd) == sorted(net.state_dict())
+    net.load_state_dict(sd)
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        y = net(torch.from_numpy(g["x"])).numpy()
+        lp = net.log_prob(torch.from_numpy(g["x"])).numpy()
+    assert y.tobytes() == g["y"].tobytes() and lp.tobytes() == g["lp"].tobytes()
+    assert np.allclose(y.sum(1), 1.0, atol=1e-6)
