@@ -347,14 +347,16 @@ def _cpu_run(kind, nproc, args, state_dict, seconds):
     t0 = time.perf_counter()
     for p in procs:
         p.start()
-    res = []
-    for _ in procs:
+    # every worker reports once; one that died (or hangs) must not hold the benchmark line up: a fixed deadline
+    res, deadline = [], time.perf_counter() + seconds + 120.0
+    while len(res) < len(procs) and time.perf_counter() < deadline:
         try:
-            res.append(q.get(timeout=seconds * 6 + 240))
+            res.append(q.get(timeout=2.0))
         except Exception:
-            res.append(None)
+            if not any(p.is_alive() for p in procs):
+                break
     for p in procs:
-        p.join(timeout=30)
+        p.join(timeout=5)
         if p.is_alive():
             p.kill()
     wall = time.perf_counter() - t0
@@ -395,7 +397,7 @@ def cpu_baseline(args, model):
     except Exception:
         ncpu_aff = ncpu
     usable = int(min(ncpu_aff, quota) if quota else ncpu_aff)
-    nproc = args.cpu_procs or max(1, min(usable, 128))
+    nproc = args.cpu_procs or max(1, min(usable - 1, 128))     # one core stays with this process
     sample = "1 game per process x %d sims/move from a fresh game (seed 20260925+i), pool %d, same network weights, %.0f s per process"
     kind = "reference"
     one, errs = _cpu_run(kind, 1, args, sd, args.cpu_seconds)

@@ -30,6 +30,10 @@ def test_kernel_stats_summary(tmp_path):
     assert [g["Name"] for g in got] == ["void tmcts::k_sim_step<false>(tm_store, int)", "tmcts_vn::k_vn_fc1(float const*)"]
     assert got[0]["Calls"] == "2" and float(got[0]["AverageNs"]) == 100.0 and got[0]["MinNs"] == "90" and got[0]["MaxNs"] == "110"
     assert abs(float(got[0]["Percentage"]) - 100.0 * 200 / 240) < 1e-2 and got[1]["LDS"] == "33792"
+    # --last N: only the last N launches of every kernel (the timed window of a bench run)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "kernel_stats.py"), str(tmp_path / "run"), str(out), "--last", "1"])
+    got = list(csv.DictReader(open(out)))
+    assert got[0]["Calls"] == "2" and got[0]["CallsAveraged"] == "1" and float(got[0]["AverageNs"]) == 110.0
 
 
 def test_pmc_traffic_summary_and_bench_reader(tmp_path, monkeypatch):
