@@ -67,14 +67,15 @@ def main(argv=None):
             sys.exit('--%s is part of the reference\'s storage / UI layer (util/Data.py, util/gui.py), which this engine '
                      'does not reimplement' % flag)
     if not args.agent_type:
-        sys.exit('--agent_type is required (ValueSim, ValueSimLP, ValueSimC)')
-    from tetris_mcts_amd import agents
-    from tetris_mcts_amd.pyTetris import Tetris
+        sys.exit('--agent_type is required (ValueSim, ValueSimLP, ValueSimC, Vanilla, VanillaC)')
+    from importlib import import_module
+    from pyTetris import Tetris                       # the reference's own two import lines (play.py:1,81-82)
+    _agent_module = import_module('agents.' + args.agent_type)
 
     env_args = ((20, 10), args.app, args.tetris_scoring, args.tetris_randomizer)
     G = args.n_games
     game = Tetris(*env_args, seed=args.seed, n_games=G)
-    agent = getattr(agents, args.agent_type)(sims=args.mcts_sims, env=Tetris, env_args=env_args, benchmark=args.benchmark,
+    agent = getattr(_agent_module, args.agent_type)(sims=args.mcts_sims, env=Tetris, env_args=env_args, benchmark=args.benchmark,
                                              online=args.online, min_visit=args.min_visit, n_games=G)
     agent.update_root(game)
 

@@ -448,3 +448,18 @@ def test_vanillac_batch_vs_oracle(oracle):
                 og[g].reset()
                 oa[g].update_root(og[g])
     assert agent.store.counter("N_GC") == sum(o.n_gc for o in oa) >= 1
+
+
+def test_play_cli_runs_a_short_game(capsys, tmp_path, monkeypatch):
+    """play.main() itself, resolving the agent and the environment through the reference's own import lines
+    (`from pyTetris import Tetris`, `import_module('agents.' + name)`, play.py:1,81-82): a few moves of ValueSimLP and of
+    VanillaC, with the per-episode log line the dashboards parse when a game ends."""
+    import play
+    from tetris_mcts_amd import model as M
+    monkeypatch.setattr(M, "EXP_PATH", str(tmp_path) + "/")
+    monkeypatch.chdir(tmp_path)
+    play.main(["--agent_type", "ValueSimLP", "--mcts_sims", "20", "--max_moves", "6", "--print_board_to_file"])
+    assert os.path.getsize(tmp_path / "board_output") == 200
+    play.main(["--agent_type", "VanillaC", "--mcts_sims", "8", "--endless", "--max_moves", "400", "--n_games", "3"])
+    out = capsys.readouterr().out
+    assert "Episode:" in out and "Lines Cleared:" in out
