@@ -9,7 +9,7 @@
  * reference pins its results, so this engine's parity with pyTetris is UNPINNED: it follows
  * ENGINE_SPEC.md (this repo's own specification) section by section.  It is written cell by
  * cell on purpose - an independent formulation from the bit-mask engine in
- * tetris_mcts_amd/csrc/engine.cuh that it checks.
+ * tetris_mcts_amd/csrc/engine.h that it checks.
  */
 #ifndef ORACLE_TETRIS_ENGINE_H
 #define ORACLE_TETRIS_ENGINE_H

@@ -1,4 +1,4 @@
-"""HIP engine (tetris_mcts_amd/csrc/engine.cuh) vs the CPU oracle engine: bit-exact packed games."""
+"""HIP engine (tetris_mcts_amd/csrc/engine.h) vs the CPU oracle engine: bit-exact packed games."""
 import numpy as np
 import pytest
 

@@ -13,7 +13,7 @@
 // of the children's records).  The raw per-action child indices live in a separate 32-byte row (GC, root statistics).
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include "engine.cuh"
+#include "engine.h"
 #include "../../include/tetris_mcts_hip.h"
 
 namespace tmcts {
