@@ -491,8 +491,7 @@ __device__ __forceinline__ void store_stat(uint32_t* st, uint32_t old_x, int vis
     *reinterpret_cast<uint4*>(st) = make_uint4((uint32_t)visit | (old_x & 0x80000000u), __float_as_uint(value),
                                                __float_as_uint(variance), __float_as_uint(root));
 }
-__device__ __forceinline__ void welford_f64(uint32_t* st, double x, double var_in) {
-    uint4 s = *reinterpret_cast<uint4*>(st);
+__device__ __forceinline__ void welford_f64(uint32_t* st, uint4 s /* the record at st, loaded by the caller */, double x, double var_in) {
     int visit = (int)(s.x & 0x7FFFFFFFu);
     float value = __uint_as_float(s.y), variance = __uint_as_float(s.z);
     if (visit == 0) {
@@ -508,8 +507,7 @@ __device__ __forceinline__ void welford_f64(uint32_t* st, double x, double var_i
     store_stat(st, s.x, visit + 1, value, variance);
 }
 // agent.cpp:496-513: the carried value is a float
-__device__ __forceinline__ void welford_f32carry(uint32_t* st, float x, float var_in) {
-    uint4 s = *reinterpret_cast<uint4*>(st);
+__device__ __forceinline__ void welford_f32carry(uint32_t* st, uint4 s /* the record at st, loaded by the caller */, float x, float var_in) {
     int visit = (int)(s.x & 0x7FFFFFFFu);
     float value = __uint_as_float(s.y), variance = __uint_as_float(s.z);
     if (visit == 0) {
@@ -529,8 +527,8 @@ __device__ __forceinline__ void welford_f32carry(uint32_t* st, float x, float va
 // is a pure function of the scores, so every lane replays the recurrence and keeps its own entry's
 // value; the observation updates are independent unless an observation repeats in the trace, which
 // ENGINE_SPEC.md rules out for app == 1 (checked, with a sequential fallback, when app > 1).
-__device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lane, int len, double v0, double var0,
-                                         bool float_carry) {
+template <bool FLOAT_CARRY>
+__device__ __forceinline__ void wave_backup_trace_t(const tm_store& S, const GP& P, int lane, int len, double v0, double var0) {
     const double gamma = S.gamma;
     double V = v0;
     float Vf = (float)v0;
@@ -540,28 +538,39 @@ __device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lan
         int i = len - 1 - base - lane;
         uint4 e = make_uint4(0, 0, 0, 0);      // (-, observation, score bits, -)
         if (lane < cnt) e = reinterpret_cast<const uint4*>(P.trace())[i];
+        // the observation's statistics are requested before the recurrence below and used after it: one load (as separate
+        // words the optimizer fetched the visit count, branched on it and fetched the rest - two trips), under the loop
+        uint32_t* st = P.stat() + (size_t)e.y * 4;
+        uint4 sv = *reinterpret_cast<const uint4*>(st);      // lanes >= cnt: entry 0 (the null observation), never stored
         double x = 0;
         float xf = 0;
+        // the carried value is a pure function of the scores: every lane replays the recurrence and keeps the value of its
+        // own entry.  (The carry type is a template parameter: as a run-time flag it put four branches into this loop.)
         for (int j = 0; j < cnt; ++j) {
-            float sj = rl_f32(__uint_as_float(e.z), j);   // wave-uniform source lane
-            if (float_carry) {
+            const float sj = rl_f32(__uint_as_float(e.z), j);   // wave-uniform source lane
+            if (FLOAT_CARRY) {
                 Vf = Vf - sj;
-                if (lane == j) xf = Vf;
-                double t = gamma * (double)Vf;
+                xf = (lane == j) ? Vf : xf;
+                const double t = gamma * (double)Vf;
                 Vf = (float)(t + (double)sj);
             } else {
                 V = V - (double)sj;
-                if (lane == j) x = V;
-                double t = gamma * V;
+                x = (lane == j) ? V : x;
+                const double t = gamma * V;
                 V = t + (double)sj;
             }
         }
+        asm volatile("" : "+v"(sv.x), "+v"(sv.y), "+v"(sv.z));
         if (lane < cnt) {
-            uint32_t* st = P.stat() + (size_t)e.y * 4;
-            if (float_carry) welford_f32carry(st, xf, varf);
-            else welford_f64(st, x, var0);
+            if (FLOAT_CARRY) welford_f32carry(st, sv, xf, varf);
+            else welford_f64(st, sv, x, var0);
         }
     }
+}
+__device__ inline void wave_backup_trace(const tm_store& S, const GP& P, int lane, int len, double v0, double var0,
+                                         bool float_carry) {
+    if (float_carry) wave_backup_trace_t<true>(S, P, lane, len, v0, var0);
+    else wave_backup_trace_t<false>(S, P, lane, len, v0, var0);
 }
 // strictly sequential form (one lane), used when an observation may repeat inside the trace
 __device__ inline void lane_backup_trace_seq(const tm_store& S, const GP& P, int len, double v0, double var0,
@@ -573,14 +582,15 @@ __device__ inline void lane_backup_trace_seq(const tm_store& S, const GP& P, int
         uint4 e = reinterpret_cast<const uint4*>(P.trace())[i];
         float sj = __uint_as_float(e.z);
         uint32_t* st = P.stat() + (size_t)e.y * 4;
+        const uint4 sv = *reinterpret_cast<const uint4*>(st);
         if (float_carry) {
             Vf = Vf - sj;
-            welford_f32carry(st, Vf, (float)var0);
+            welford_f32carry(st, sv, Vf, (float)var0);
             double t = gamma * (double)Vf;
             Vf = (float)(t + (double)sj);
         } else {
             V = V - (double)sj;
-            welford_f64(st, V, var0);
+            welford_f64(st, sv, V, var0);
             double t = gamma * V;
             V = t + (double)sj;
         }
