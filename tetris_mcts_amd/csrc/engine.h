@@ -139,13 +139,23 @@ __device__ __forceinline__ void lock_piece(uint16_t* rows, Piece& p, const EngCf
             rows[r] = (uint16_t)(rows[r] | (((bits << (p.x + 3)) >> 3) & 0x3FFu));
         }
     }
-    int n = 0, dst = 19;
-    for (int r = 19; r >= 0; --r) {
-        uint16_t v = rows[r];
-        if (v == 0x3FF) { n += 1; continue; }
-        rows[dst--] = v;
+    // only the (at most four) rows the piece touched can have become full: most locks clear nothing and skip the compaction
+    int n = 0;
+    bool any_full = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = p.y + i;
+        if (((mask >> (4 * i)) & 0xFu) && rows[r] == 0x3FF) any_full = true;
     }
-    for (; dst >= 0; --dst) rows[dst] = 0;
+    if (any_full) {
+        int dst = 19;
+        for (int r = 19; r >= 0; --r) {
+            uint16_t v = rows[r];
+            if (v == 0x3FF) { n += 1; continue; }
+            rows[dst--] = v;
+        }
+        for (; dst >= 0; --dst) rows[dst] = 0;
+    }
     p.line_clears += n;
     if (n > 0) {
         if (line_stats) line_stats[n - 1] += 1;
@@ -164,29 +174,37 @@ __device__ __forceinline__ void lock_piece(uint16_t* rows, Piece& p, const EngCf
     spawn(rows, p, cfg);
 }
 
-// ENGINE_SPEC.md section 4: one play(a)
-__device__ __forceinline__ void play(uint16_t* rows, Piece& p, const EngCfg& cfg, int a, int* line_stats) {
+// ENGINE_SPEC.md section 4: one play(a).  The piece locks at ONE place in the code: the three ways to lock (hard drop, a
+// blocked soft drop, gravity) only raise a flag, so lanes of a wavefront that step different games with different actions
+// run lock + line clear + spawn (the expensive part: the 7-bag shuffle is six 64-bit hashes) together, once, instead of
+// once per call site.
+// `drop_rows` >= 0: the caller already knows how many rows the piece can fall (computed by the lanes of a wave together,
+// hard_drop_rows below); -1: found here, row by row.
+__device__ __forceinline__ void play(uint16_t* rows, Piece& p, const EngCfg& cfg, int a, int* line_stats, int drop_rows = -1) {
     if (p.flags & 1) return;
-    bool locked = false;
+    bool do_lock = false;
     uint32_t mask = PIECE_MASK[p.piece][p.rot];
     if (a == 1) {
         if (!collides(rows, mask, p.x - 1, p.y)) p.x -= 1;
     } else if (a == 2) {
         if (!collides(rows, mask, p.x + 1, p.y)) p.x += 1;
     } else if (a == 3) {
-        while (!collides(rows, mask, p.x, p.y + 1)) {
-            p.y += 1;
-            if (cfg.scoring == 0) p.score += 2;
+        if (drop_rows >= 0) {
+            p.y += drop_rows;
+            if (cfg.scoring == 0) p.score += 2 * drop_rows;
+        } else {
+            while (!collides(rows, mask, p.x, p.y + 1)) {
+                p.y += 1;
+                if (cfg.scoring == 0) p.score += 2;
+            }
         }
-        lock_piece(rows, p, cfg, line_stats);
-        locked = true;
+        do_lock = true;
     } else if (a == 4) {
         if (!collides(rows, mask, p.x, p.y + 1)) {
             p.y += 1;
             if (cfg.scoring == 0) p.score += 1;
         } else {
-            lock_piece(rows, p, cfg, line_stats);
-            locked = true;
+            do_lock = true;
         }
     } else if (a == 5 || a == 6) {
         if (p.piece != 1) {
@@ -202,13 +220,24 @@ __device__ __forceinline__ void play(uint16_t* rows, Piece& p, const EngCfg& cfg
             }
         }
     }
-    if (locked) return;
-    p.drop_ctr += 1;
-    if (p.drop_ctr >= cfg.app) {
-        p.drop_ctr = 0;
-        if (!collides(rows, PIECE_MASK[p.piece][p.rot], p.x, p.y + 1)) p.y += 1;
-        else lock_piece(rows, p, cfg, line_stats);
+    if (!do_lock) {      // an action that locked the piece is not followed by gravity
+        p.drop_ctr += 1;
+        if (p.drop_ctr >= cfg.app) {
+            p.drop_ctr = 0;
+            if (!collides(rows, PIECE_MASK[p.piece][p.rot], p.x, p.y + 1)) p.y += 1;
+            else do_lock = true;
+        }
     }
+    if (do_lock) lock_piece(rows, p, cfg, line_stats);
+}
+
+// How many rows the falling piece of the game in `slot` can fall (the hard drop's loop), by the lanes of a wave together:
+// lane r tests the piece r+1 rows down (rows beyond the floor are solid), the first lane that collides gives the answer.
+__device__ __forceinline__ int hard_drop_rows(const uint32_t* slot, int lane) {
+    Piece p;
+    load_fields(slot, p);
+    const bool hit = lane > 20 || collides(reinterpret_cast<const uint16_t*>(slot), PIECE_MASK[p.piece][p.rot], p.x, p.y + 1 + lane);
+    return __ffsll((long long)__ballot(hit)) - 1;
 }
 
 // new environment (ENGINE_SPEC.md section 6: spawns piece(0))

@@ -385,10 +385,11 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
     for (int t = lane; t < 7 * GAME_DW; t += 64) L.slots[t >> 4][t & 15] = L.slots[7][t & 15];
     wave_sync();
     EngCfg cfg{S.app, S.scoring, S.randomizer};
+    const int drop = hard_drop_rows(L.slots[7], lane);       // for the successor of action 3: 21 lanes instead of a 20-step loop in one
     if (lane < 7) {
         Piece p;
         load_fields(L.slots[lane], p);
-        play(reinterpret_cast<uint16_t*>(L.slots[lane]), p, cfg, lane, nullptr);
+        play(reinterpret_cast<uint16_t*>(L.slots[lane]), p, cfg, lane, nullptr, drop);
         store_fields(L.slots[lane], p);
     }
     wave_sync();
