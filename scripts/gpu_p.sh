@@ -1,6 +1,6 @@
 #!/bin/bash
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q --maxfail=6 -k "env_step or state_injection or (sampled_seeds and ValueSim-20)" > $OUT/p.pytest.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q --maxfail=6 -k "env_step or with_gc or golden_runs or vanilla_batch or (sampled_seeds and ValueSim-20)" > $OUT/p.pytest.log 2>&1
 echo "pytest rc=$?"; tail -n 4 $OUT/p.pytest.log | cut -c1-300
 timeout 600 python bench.py --no-cpu-baseline > $OUT/p.bench.json 2> $OUT/p.bench.err
 python - <<PY

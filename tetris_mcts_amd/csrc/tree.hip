@@ -87,6 +87,7 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ uint32_t shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 // wave-uniform source lane: v_readlane_b32 (scalar path, a few cycles) instead of an LDS-crossbar ds_bpermute
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+#define GSV(snap, word) ((int)rl_u32((uint32_t)(snap), (word)))     /* word `word` of a control-block snapshot */
 __device__ __forceinline__ float rl_f32(float v, int src) { return __uint_as_float(rl_u32(__float_as_uint(v), src)); }
 // DPP exchanges inside an 8-lane group (no LDS, no scalar round trip): partner = lane^1, lane^2, 7-lane
 __device__ __forceinline__ uint32_t dpp_x1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
@@ -262,11 +263,21 @@ __device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, u
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane);
 __device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, int lane, long long budget);
 
+// `gsv`: the wave's snapshot of the game's control block (word i in lane i), valid when nothing in this launch has changed
+// the free-list words yet (the expansion's first attempt); has_gsv = false: read them from memory (sequential retries,
+// update_root).
 __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, WaveLds& L, int g, int n, int lane,
-                                      int& r_idx, int& r_obs) {
+                                      int& r_idx, int& r_obs, bool has_gsv = false, int gsv = 0) {
     const bool act = lane < n;
     const uint32_t* my = L.slots[act ? lane : 0];
     const uint32_t mask = (uint32_t)S.table_cap - 1u;
+    // with the snapshot the free-list tops are known now: fetch the n top entries of both lists under the table lookups
+    int top_n = 0, top_o = 0;
+    if (has_gsv) {
+        const int nf = GSV(gsv, TM_GS_NFREE_NODE) - 1 - lane, of = GSV(gsv, TM_GS_NFREE_OBS) - 1 - lane;
+        if (act && nf >= 0) top_n = P.fnode()[nf];
+        if (act && of >= 0) top_o = P.fobs()[of];
+    }
     uint64_t h = hash_game(my);
     // 1. candidates that are equal to an earlier candidate reuse its node (dict hit in the reference)
     int dup = lane;
@@ -283,7 +294,7 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     bool isnew = uniq && !found && !full;
     uint64_t need = __ballot(isnew);
     int cnt = __popcll(need);
-    int nfree = P.gs()[TM_GS_NFREE_NODE];
+    int nfree = has_gsv ? GSV(gsv, TM_GS_NFREE_NODE) : P.gs()[TM_GS_NFREE_NODE];
     if (__any(full)) { if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_TABLE); }
     if (cnt > nfree) {
         // Pool exhausted: the reference reclaims unreachable nodes at exactly this pop
@@ -295,12 +306,17 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         return;
     }
     int idx = found;
-    if (isnew) idx = P.fnode()[nfree - 1 - __popcll(need & ((1ull << lane) - 1ull))];
+    {
+        const int rank = __popcll(need & ((1ull << lane) - 1ull));
+        if (has_gsv) { const int v = (int)shfl_u32((uint32_t)top_n, rank); if (isnew) idx = v; }
+        else if (isnew) idx = P.fnode()[nfree - 1 - rank];
+    }
     if (cnt) {
         // lowest index ever allocated (GC skips clearing what was never written)
         int lo = 0x7FFFFFFF;
         for (int b = 0; b < n; ++b) lo = min(lo, ((need >> b) & 1ull) ? (int)rl_u32((uint32_t)idx, b) : 0x7FFFFFFF);
-        if (lane == 0) { P.gs()[TM_GS_NFREE_NODE] = nfree - cnt; if (lo < P.gs()[TM_GS_LOW_NODE]) P.gs()[TM_GS_LOW_NODE] = lo; }
+        const int low_seen = has_gsv ? GSV(gsv, TM_GS_LOW_NODE) : P.gs()[TM_GS_LOW_NODE];
+        if (lane == 0) { P.gs()[TM_GS_NFREE_NODE] = nfree - cnt; if (lo < low_seen) P.gs()[TM_GS_LOW_NODE] = lo; }
     }
     table_insert_seq(P.ntab(), mask, need, n, lane, h, ins, idx, L.misc);
     // 3. observations of the new nodes (agents/agent.py:112-128)
@@ -322,13 +338,18 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     bool onew = ouniq && !ofound && !ofull;
     uint64_t oneed = __ballot(onew);
     int ocnt = __popcll(oneed);
-    int onfree = P.gs()[TM_GS_NFREE_OBS];
+    int onfree = has_gsv ? GSV(gsv, TM_GS_NFREE_OBS) : P.gs()[TM_GS_NFREE_OBS];
     int o = ofound;
-    if (onew) o = P.fobs()[onfree - 1 - __popcll(oneed & ((1ull << lane) - 1ull))];
+    {
+        const int rank = __popcll(oneed & ((1ull << lane) - 1ull));
+        if (has_gsv) { const int v = (int)shfl_u32((uint32_t)top_o, rank); if (onew) o = v; }
+        else if (onew) o = P.fobs()[onfree - 1 - rank];
+    }
     if (ocnt) {
         int lo = 0x7FFFFFFF;
         for (int b = 0; b < n; ++b) lo = min(lo, ((oneed >> b) & 1ull) ? (int)rl_u32((uint32_t)o, b) : 0x7FFFFFFF);
-        if (lane == 0) { P.gs()[TM_GS_NFREE_OBS] = onfree - ocnt; if (lo < P.gs()[TM_GS_LOW_OBS]) P.gs()[TM_GS_LOW_OBS] = lo; }
+        const int olow_seen = has_gsv ? GSV(gsv, TM_GS_LOW_OBS) : P.gs()[TM_GS_LOW_OBS];
+        if (lane == 0) { P.gs()[TM_GS_NFREE_OBS] = onfree - ocnt; if (lo < olow_seen) P.gs()[TM_GS_LOW_OBS] = lo; }
     }
     table_insert_seq(P.otab(), mask, oneed, n, lane, ho, oins, o, L.misc + 8);
     if (onew) {
@@ -379,7 +400,7 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
 // redone - the successors already inserted are transposition hits, the others pop from the rebuilt free list in order.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
-                                   uint32_t self_sc /* float bits of the leaf's own score */, uint32_t& hdr_out) {
+                                   uint32_t self_sc /* float bits of the leaf's own score */, uint32_t& hdr_out, int gsv) {
     if (lane < GAME_DW) L.slots[7][lane] = P.game()[(size_t)leaf * GAME_DW + lane];
     wave_sync();
     for (int t = lane; t < 7 * GAME_DW; t += 64) L.slots[t >> 4][t & 15] = L.slots[7][t & 15];
@@ -394,7 +415,7 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
     }
     wave_sync();
     int idx, o;
-    wave_new_nodes(S, P, L, g, 7, lane, idx, o);
+    wave_new_nodes(S, P, L, g, 7, lane, idx, o, true, gsv);
     if (idx < 0) {
         // slow path: sequential new_node with a GC at the exhausting pop (rare: once per ~50 moves)
         int out_idx = 0, out_o = 0;
@@ -618,11 +639,11 @@ __device__ inline bool trace_has_repeat(const GP& P, int lane, int len, const in
 // ---------------------------------------------------------------------------------------------------
 // the back half of a simulation: ValueSim.py:83-94 / ValueSimLP.py:59-70 / agent.cpp:432-446,458
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L, int lane) {
-    const int len = P.gs()[TM_GS_TRACE_LEN];
-    const int leaf_end = P.gs()[TM_GS_LEAF_END];
-    const int k = P.gs()[TM_GS_K_EVAL];
-    const int leaf_score = P.gs()[TM_GS_LEAF_SCORE];
+__device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L, int lane, int gsv) {
+    const int len = GSV(gsv, TM_GS_TRACE_LEN);
+    const int leaf_end = GSV(gsv, TM_GS_LEAF_END);
+    const int k = GSV(gsv, TM_GS_K_EVAL);
+    const int leaf_score = GSV(gsv, TM_GS_LEAF_SCORE);
     const int kind = S.kind;
     const bool fcarry = (kind == TM_KIND_CPPAGENT_LP || kind == TM_KIND_CPPAGENT || kind == TM_KIND_VANILLA_C);
     double v0 = 0, var0 = 0;
@@ -681,7 +702,7 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
         seq = trace_has_repeat(P, lane, len, nullptr, 0);
     if (seq) { if (lane == 0) lane_backup_trace_seq(S, P, len, v0, var0, fcarry); }
     else wave_backup_trace(S, P, lane, len, v0, var0, fcarry);
-    if (lane == 0) { P.gs()[TM_GS_PENDING] = 0; P.gs()[TM_GS_N_SIMS] += 1; }
+    if (lane == 0) { P.gs()[TM_GS_PENDING] = 0; P.gs()[TM_GS_N_SIMS] = GSV(gsv, TM_GS_N_SIMS) + 1; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -690,13 +711,13 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
 // ---------------------------------------------------------------------------------------------------
 template <bool VANILLA>
 __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
-                                                  int leaf_end, uint32_t self_o, uint32_t self_sc) {
+                                                  int leaf_end, uint32_t self_o, uint32_t self_sc, int gsv) {
     const long long tc0 = __builtin_readcyclecounter();
     const int kind = S.kind;
     int k_eval = 0;
     if (!leaf_end) {
         uint32_t lh;
-        if (!wave_expand(S, P, L, g, lane, leaf, self_sc, lh)) {
+        if (!wave_expand(S, P, L, g, lane, leaf, self_sc, lh, gsv)) {
             if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
             if (lane == 0) P.gs()[TM_GS_PENDING] = 2;
             return;
@@ -719,7 +740,7 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
                 P.eval_obs()[lane] = on ? (int)L.misc[24 + lane] : 0;
             }
         }
-        if (lane == 0) P.gs()[TM_GS_N_EXPAND] += 1;
+        if (lane == 0) P.gs()[TM_GS_N_EXPAND] = GSV(gsv, TM_GS_N_EXPAND) + 1;
     } else {
         if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
     }
@@ -729,7 +750,7 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
         gs[TM_GS_PENDING] = 1;
         gs[TM_GS_GC_RETRY] = 0;
         gs[TM_GS_K_EVAL] = k_eval;
-        gs[TM_GS_N_EVAL] += k_eval;
+        gs[TM_GS_N_EVAL] = GSV(gsv, TM_GS_N_EVAL) + k_eval;
     }
 }
 
@@ -737,13 +758,13 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
 // the front half: select_trace_obs (core.h:167-224), then expansion and evaluation requests
 // ---------------------------------------------------------------------------------------------------
 template <bool VANILLA>
-__device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, int g, int lane) {
+__device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, int g, int lane, int gsv) {
     const long long tc_start = __builtin_readcyclecounter();
     if (lane < 32) L.misc[lane] = S.rng[(size_t)g * 32 + lane];      // glibc rand() state (31 words), used by check_low only
     wave_sync();
-    int rng_pos = P.gs()[TM_GS_RNG_POS];
+    int rng_pos = GSV(gsv, TM_GS_RNG_POS);
     const int rng_pos0 = rng_pos;
-    int idx = P.gs()[TM_GS_ROOT];
+    int idx = GSV(gsv, TM_GS_ROOT);
     int len = 0;
     uint32_t hdr = 0, self_o = 0;
     const int low = S.low;
@@ -932,11 +953,11 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         gs[TM_GS_LEAF] = leaf;
         gs[TM_GS_LEAF_END] = leaf_end | (overflow ? 1 : 0);
         gs[TM_GS_LEAF_SCORE] = leaf_score;
-        gs[TM_GS_TRACE_SUM] += len;
-        if (len > gs[TM_GS_MAX_TRACE]) gs[TM_GS_MAX_TRACE] = len;
-        if (nq_fallback) gs[TM_GS_N_NQ_FALLBACK] += nq_fallback;
-        gs[TM_GS_SIM_STARTED] += 1;
-        gs[TM_GS_N_WALK_MISS] += n_miss;
+        gs[TM_GS_TRACE_SUM] = GSV(gsv, TM_GS_TRACE_SUM) + len;
+        if (len > GSV(gsv, TM_GS_MAX_TRACE)) gs[TM_GS_MAX_TRACE] = len;
+        if (nq_fallback) gs[TM_GS_N_NQ_FALLBACK] = GSV(gsv, TM_GS_N_NQ_FALLBACK) + nq_fallback;
+        gs[TM_GS_SIM_STARTED] = GSV(gsv, TM_GS_SIM_STARTED) + 1;
+        gs[TM_GS_N_WALK_MISS] = GSV(gsv, TM_GS_N_WALK_MISS) + n_miss;
 #ifdef TM_PROF_WALK
         gs[TM_GS_CYC_WALK_MEM] = (int)prof_mem;
 #endif
@@ -945,7 +966,7 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         if (lane < 32) S.rng[(size_t)g * 32 + lane] = rng_keep;
         if (lane == 0) P.gs()[TM_GS_RNG_POS] = rng_pos;
     }
-    wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end | (overflow ? 1 : 0), self_o, self_sc);
+    wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end | (overflow ? 1 : 0), self_o, self_sc, gsv);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1224,19 +1245,24 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     GP P = game_ptrs(S, g);
     WaveLds& L = lds[w];
     int32_t* gs = P.gs();
-    if (gs[TM_GS_GC_PHASE] != 0) {
+    // The game's control block (64 words) in one coalesced load: word i in lane i, read with v_readlane.  A word is read
+    // from the snapshot only before this launch writes it (the halves below write each word once, from lane 0); the
+    // snapshot is taken again after a collection, which rewrites the free-list words.
+    int gsv = gs[lane];
+    if (GSV(gsv, TM_GS_GC_PHASE) != 0) {
         // this game is collecting garbage: one slice per launch (S.gc_slice_cycles; 0 = to completion), no simulation
         // (catch-up launches pass TM_SIM_GC_FULL: only laggards are left, nobody is held up by a collection run to its end)
         const bool sliced = S.gc_slice_cycles > 0 && !(flags & TM_SIM_GC_FULL);
         if (!gc_run(S, P, g, lane, sliced ? (long long)S.gc_slice_cycles : -1)) return;
+        gsv = gs[lane];
     }
-    const int pend = gs[TM_GS_PENDING];
+    const int pend = GSV(gsv, TM_GS_PENDING);
     if (pend == 2) {
         // the simulation suspended in its expansion: redo the expansion of its leaf, post the evaluation requests
-        const int leaf = gs[TM_GS_LEAF];
+        const int leaf = GSV(gsv, TM_GS_LEAF);
         const uint32_t self_o = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_OBS];
         const uint32_t self_sc = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_SCORE];
-        wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc);
+        wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc, gsv);
         return;
     }
 #ifndef TM_NO_SETPRIO
@@ -1244,7 +1270,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     // 69 nodes, maximum 160 at 4096 games).  The games with the longest walks get issue priority over the three other
     // waves of their SIMD (static priority: the loser pays little, it was going to wait for this wave anyway).
     {
-        const int last_len = gs[TM_GS_TRACE_LEN];
+        const int last_len = GSV(gsv, TM_GS_TRACE_LEN);
         if (last_len >= 112) __builtin_amdgcn_s_setprio(3);
         else if (last_len >= 88) __builtin_amdgcn_s_setprio(2);
         else if (last_len >= 72) __builtin_amdgcn_s_setprio(1);
@@ -1252,14 +1278,14 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
 #endif
     const long long t0 = __builtin_readcyclecounter();
     if ((flags & TM_SIM_BACKUP) && pend == 1) {
-        wave_sim_back(S, P, L, lane);
+        wave_sim_back(S, P, L, lane, gsv);
         __threadfence_block();
     }
     const long long t1 = __builtin_readcyclecounter();
     if (lane == 0) gs[TM_GS_CYC_BACK] = (int)(t1 - t0);
     // the per-move quota (tm_move_begin): games that lost launches to a collection catch up in extra launches
-    if ((flags & TM_SIM_FRONT) && gs[TM_GS_SIM_STARTED] < gs[TM_GS_SIM_TARGET])
-        wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane);
+    if ((flags & TM_SIM_FRONT) && GSV(gsv, TM_GS_SIM_STARTED) < GSV(gsv, TM_GS_SIM_TARGET))
+        wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane, gsv);
     else if (lane < S.eval_slots) P.eval_obs()[lane] = 0;      // nothing started: no request (the evaluator skips empty slots)
 }
 
