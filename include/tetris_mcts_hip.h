@@ -143,6 +143,16 @@ int tm_env_info(const tm_store *s, int32_t *out /* [G][8]: end, score, lines, co
 
 /* tree agent */
 int tm_update_root(const tm_store *s, void *stream);                                    /* agent.update_root(game) */
+/* TreeAgent's single calls as agents.cppmodule.agent exports them (agent.cpp:829 new_node, :833 expand, :828 remove_nodes;
+ * agents/agent.py:90-145,246-257), one game state per tree.  games: device [G][16] packed games (the layout of
+ * s->env_game; a pyTetris buffer in the reference); mask: device [G] or NULL (all games); out_idx: device [G] or NULL,
+ * the node index new_node(game) returned (-1 where masked out).  tm_tree_expand = idx = new_node(game), then
+ * child[idx][a] = new_node(game.play(a)) for the seven actions (agent.cpp:201-208), with the record's unique-child list.
+ * A collection runs at the exhausting pop exactly as in the reference, so - as there - `game` must be reachable from the
+ * root (or the pool must not run dry) for its node to survive the call. */
+int tm_tree_new_node(const tm_store *s, const uint32_t *games, const uint8_t *mask, int32_t *out_idx, void *stream);
+int tm_tree_expand(const tm_store *s, const uint32_t *games, const uint8_t *mask, int32_t *out_idx, void *stream);
+int tm_tree_remove_nodes(const tm_store *s, const uint8_t *mask, void *stream);             /* agent.remove_nodes() */
 /* One move of every game = tm_move_begin(sims), then launches of tm_sim_step(BACKUP|FRONT) each followed by the leaf
  * evaluator, until tm_sims_remaining reports 0: a launch starts a new simulation for a game only while the game has
  * quota left, backs up its pending one, or - when the game's node pool ran dry - runs one slice of its garbage

@@ -44,6 +44,9 @@ def lib():
         L.orc_agent_play.argtypes = [vp, i32]
         L.orc_agent_play.restype = i32
         L.orc_agent_compute_stats.argtypes = [vp, i32, vp]
+        L.orc_agent_new_node.restype, L.orc_agent_new_node.argtypes = i32, [vp, vp]
+        L.orc_agent_expand_game.argtypes = [vp, vp]
+        L.orc_agent_remove_nodes.argtypes = [vp]
         for name in ("child", "score", "n_to_o", "visit", "value", "variance", "end_obs", "obs_state", "games",
                      "stats", "mem_state", "mem_value", "mem_variance", "mem_visit", "rng"):
             f = getattr(L, "orc_agent_" + name)
@@ -110,6 +113,11 @@ class Game:
 
     def reset(self):
         lib().orc_game_reset(ptr(self.g), *self.cfg, ptr(self.line_stats))
+
+    def copy_from(self, other):
+        self.cfg = other.cfg
+        self.g[...] = other.g
+        self.line_stats[...] = other.line_stats
 
     def copy(self):
         o = Game.__new__(Game)
@@ -178,6 +186,21 @@ class Agent:
 
     def play(self, sims):
         return self.L.orc_agent_play(self.h, sims)
+
+    # TreeAgent's single calls (agent.cpp:212-218,265-270,337; agents/agent.py:90-145,246-257)
+    def new_node(self, game):
+        return self.L.orc_agent_new_node(self.h, ptr(game.g))
+
+    def expand(self, game):
+        self.L.orc_agent_expand_game(self.h, ptr(game.g))
+
+    def remove_nodes(self):
+        self.L.orc_agent_remove_nodes(self.h)
+
+    def compute_stats(self):
+        out = np.zeros((3, 7), np.float32)
+        self.L.orc_agent_compute_stats(self.h, self.root, ptr(out))
+        return out
 
     def _arr(self, name, dtype, shape):
         p = getattr(self.L, "orc_agent_" + name)(self.h)

@@ -466,6 +466,58 @@ def gen_vanillac():
         json.dump(out, f)
 
 
+def treeagent_script(steps, script_seed):
+    """(action expanded below the root, action played) per step: the script both the reference and the replays follow."""
+    rs = np.random.RandomState(script_seed)
+    return [[int(rs.randint(7)), int(rs.randint(7))] for _ in range(steps)]
+
+
+def gen_treeagent():
+    """ref_treeagent.json: the reference's compiled TreeAgent (agents/cppmodule/agent.cpp:84-413, exported at :825-833)
+    driven through its single calls - update_root, expand(game), new_node(game) - on the oracle engine.  Per step: expand
+    the root, ask new_node for its seven successors (existing nodes: their indices), expand one successor, ask new_node
+    for ITS successors, play a scripted action, update_root, new_node(root game).  The index sequences pin new_node /
+    expand / the collection at an exhausted pool (run 2: pool of 1000) as the pybind module itself answers them."""
+    ref_shims.install()
+    from pyTetris import Tetris
+    agent_mod = sys.modules["agents.cppmodule.agent"]
+    out = []
+    for max_nodes, seed, steps, sseed in ((6000, 81, 80, 5), (1000, 82, 260, 6)):
+        agent = agent_mod.TreeAgent(max_nodes, True, 0)
+        game = Tetris((20, 10), 1, 0, 0, seed)
+        tmp, tmp2 = Tetris((20, 10), 1, 0, 0, 0), Tetris((20, 10), 1, 0, 0, 0)
+        agent.update_root(game)
+        rec = []
+        for a1, a in treeagent_script(steps, sseed):
+            agent.expand(game)
+            kids = []
+            for b in range(7):
+                tmp.copy_from(game)
+                tmp.play(b)
+                kids.append(int(agent.new_node(tmp)))
+            tmp.copy_from(game)
+            tmp.play(a1)
+            agent.expand(tmp)
+            gk = []
+            for b in range(7):
+                tmp2.copy_from(tmp)
+                tmp2.play(b)
+                gk.append(int(agent.new_node(tmp2)))
+            game.play(a)
+            agent.update_root(game)
+            root = int(agent.new_node(game))
+            ended = bool(game.end)
+            if ended:
+                game.reset()
+                agent.update_root(game)
+            rec.append([kids, gk, root, int(ended)])
+        out.append(dict(max_nodes=max_nodes, seed=seed, script_seed=sseed, steps=rec))
+        print("TreeAgent pool %d: %d steps, highest index %d, %d episode ends" % (
+            max_nodes, len(rec), max(max(r[0] + r[1]) for r in rec), sum(r[3] for r in rec)))
+    with open(os.path.join(OUT, "ref_treeagent.json"), "w") as f:
+        json.dump(out, f)
+
+
 def gen_dist():
     """ref_dist.npz: the reference's distribution helpers (core.h:387-449, compiled through oracle/ref_dist_shim.cpp) on
     seeded categorical distributions.  Only cases in which the reference's write to result[bins] adds exactly 0 or does not
@@ -617,7 +669,7 @@ def gen_training():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training", "vanillac", "dist", "distnet"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training", "vanillac", "dist", "distnet", "treeagent"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -639,6 +691,8 @@ if __name__ == "__main__":
         gen_training()
     if "vanillac" in which:
         gen_vanillac()
+    if "treeagent" in which:
+        gen_treeagent()
     if "dist" in which:
         gen_dist()
     if "distnet" in which:

@@ -463,3 +463,68 @@ def test_play_cli_runs_a_short_game(capsys, tmp_path, monkeypatch):
     play.main(["--agent_type", "VanillaC", "--mcts_sims", "8", "--endless", "--max_moves", "400", "--n_games", "3"])
     out = capsys.readouterr().out
     assert "Episode:" in out and "Lines Cleared:" in out
+
+
+# ---- TreeAgent's single calls (agent.cpp:825-833): update_root / expand(game) / new_node(game) / remove_nodes ----
+def _tree_agent(G, max_nodes, seed):
+    from tetris_mcts_amd import agents
+    from tetris_mcts_amd.pyTetris import Tetris
+    env_args = ((20, 10), 1, 0, 0)
+    game = Tetris(*env_args, seed=seed, n_games=G)
+    agent = agents.ValueSimC(sims=1, env=Tetris, env_args=env_args, n_games=G, max_nodes=max_nodes,
+                             evaluator=hash_eval_torch)
+    return game, agent, (lambda: Tetris(*env_args, seed=0, n_games=G))
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_tree_single_calls_vs_reference_treeagent(golden_dir, idx):
+    """tests/golden/ref_treeagent.json: every index the reference's compiled TreeAgent returned from new_node(game) while
+    being driven through update_root / expand(game), across two collections at a 1000-node pool (run 1)."""
+    from test_oracle_agent import replay_treeagent, treeagent_script
+    with open(os.path.join(golden_dir, "ref_treeagent.json")) as f:
+        r = json.load(f)[idx]
+    game, agent, mk = _tree_agent(1, r["max_nodes"], r["seed"])
+
+    def check(i, kids, gk, root, ended):
+        assert [kids, gk, root, int(ended)] == r["steps"][i], (i, kids, gk, root, ended, r["steps"][i])
+    replay_treeagent(agent, game, mk, treeagent_script(len(r["steps"]), r["script_seed"]), check)
+    assert not bool(agent.store.errors().any().item())
+    assert agent.store.counter("N_GC") == (2 if idx == 1 else 0)
+
+
+def test_tree_single_calls_batch_vs_oracle(oracle):
+    """Four trees driven at once through the single calls, pool 1200: indices, then the whole reachable tree, against
+    one oracle agent per game; remove_nodes() as a call of its own in the middle."""
+    from test_oracle_agent import replay_treeagent, treeagent_script
+    G, N, seed, steps = 4, 1200, 300, 200
+    script = treeagent_script(steps, 11)
+    game, agent, mk = _tree_agent(G, N, seed)
+    got = []
+
+    def rec(i, kids, gk, root, ended):
+        got.append((np.stack(kids, 1).tolist(), np.stack(gk, 1).tolist(), np.asarray(root).tolist(),
+                    np.asarray(ended).astype(int).tolist()))
+        if i == 60:
+            agent.remove_nodes()
+    replay_treeagent(agent, game, mk, script, rec)
+    assert not bool(agent.store.errors().any().item())
+    gcs = 0
+    for g in range(G):
+        oa, og = oracle.Agent(3, max_nodes=N), oracle.Game(seed=seed + g)
+
+        def check(i, kids, gk, root, ended):
+            assert (kids, gk, root, int(ended)) == (got[i][0][g], got[i][1][g], got[i][2][g], got[i][3][g]), (g, i)
+            if i == 60:
+                oa.remove_nodes()
+        replay_treeagent(oa, og, lambda: oracle.Game(seed=0), script, check)
+        gcs += oa.n_gc
+        dev, ref = agent.store.export_game(g), oa.arrays()
+        mark = np.zeros(N, np.uint8)
+        oracle.lib().orc_get_all_childs(oa.root, oracle.ptr(ref["child"]), N, oracle.ptr(mark))
+        occ = np.nonzero(mark)[0]
+        assert agent.store.t["gs"][g, 0].item() == oa.root
+        for k in ("child", "score", "n_to_o"):
+            assert np.array_equal(dev[k][occ], ref[k][occ]), (k, g)
+        oo = np.unique(ref["n_to_o"][occ])
+        assert dev["end_obs"][oo].tobytes() == ref["end_obs"][oo].tobytes()
+    assert gcs >= 2 * G and agent.store.counter("N_GC") == gcs

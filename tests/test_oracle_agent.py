@@ -191,3 +191,56 @@ def test_agent_oracle_replays_reference_vanillac(oracle, golden_dir, idx):
             a.update_root(g)
     assert a.n_gc >= (1 if idx == 2 else 0)
     a.close()
+
+
+def treeagent_script(steps, script_seed):
+    """tests/golden/make_golden.py:treeagent_script (the golden stores the seed, not the actions)."""
+    rs = np.random.RandomState(script_seed)
+    return [[int(rs.randint(7)), int(rs.randint(7))] for _ in range(steps)]
+
+
+def replay_treeagent(agent, game, make_game, script, on_step):
+    """Drive an agent through the steps of tests/golden/ref_treeagent.json with its single calls.  `agent` offers
+    update_root / expand / new_node, games offer play / copy_from / end / reset; on_step(i, kids, gk, root, ended)."""
+    tmp, tmp2 = make_game(), make_game()
+    agent.update_root(game)
+    for i, (a1, a) in enumerate(script):
+        agent.expand(game)
+        kids = []
+        for b in range(7):
+            tmp.copy_from(game)
+            tmp.play(b)
+            kids.append(agent.new_node(tmp))
+        tmp.copy_from(game)
+        tmp.play(a1)
+        agent.expand(tmp)
+        gk = []
+        for b in range(7):
+            tmp2.copy_from(tmp)
+            tmp2.play(b)
+            gk.append(agent.new_node(tmp2))
+        game.play(a)
+        agent.update_root(game)
+        root = agent.new_node(game)
+        ended = game.end
+        if np.any(ended):
+            game.reset(ended) if np.ndim(ended) else game.reset()
+            agent.update_root(game)
+        on_step(i, kids, gk, root, ended)
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_agent_oracle_replays_reference_treeagent_single_calls(oracle, golden_dir, idx):
+    """tests/golden/ref_treeagent.json: the reference's compiled TreeAgent answering update_root / expand(game) /
+    new_node(game) (agent.cpp:825-833) - every index it returned, across collections at a 1000-node pool (run 1)."""
+    with open(os.path.join(golden_dir, "ref_treeagent.json")) as f:
+        r = json.load(f)[idx]
+    a = oracle.Agent(3, max_nodes=r["max_nodes"], cpp_occupied=True)
+    g = oracle.Game(seed=r["seed"])
+
+    def check(i, kids, gk, root, ended):
+        want = r["steps"][i]
+        assert [kids, gk, root, int(ended)] == want, (i, kids, gk, root, ended, want)
+    replay_treeagent(a, g, lambda: oracle.Game(seed=0), treeagent_script(len(r["steps"]), r["script_seed"]), check)
+    assert a.error == 0
+    assert (a.n_gc >= 2) if idx == 1 else (a.n_gc == 0)

@@ -35,6 +35,9 @@ SYMBOLS = {
     "tm_env_render": [C.POINTER(TmStore), vp, vp],
     "tm_env_info": [C.POINTER(TmStore), vp, vp],
     "tm_update_root": [C.POINTER(TmStore), vp],
+    "tm_tree_new_node": [C.POINTER(TmStore), vp, vp, vp, vp],
+    "tm_tree_expand": [C.POINTER(TmStore), vp, vp, vp, vp],
+    "tm_tree_remove_nodes": [C.POINTER(TmStore), vp, vp],
     "tm_sim_step": [C.POINTER(TmStore), i32, vp],
     "tm_move_begin": [C.POINTER(TmStore), i32, vp],
     "tm_sims_remaining": [C.POINTER(TmStore), vp, vp],

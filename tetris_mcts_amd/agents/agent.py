@@ -140,13 +140,33 @@ class TreeAgent(Agent):
         p = s[:, 0] / s[:, 0].sum(axis=1, keepdims=True)
         return p[0] if self.n_games == 1 else p
 
+    def new_node(self, game):
+        """Node index of `game`'s state in every tree, inserted if new (agents/agent.py:90-130, agent.cpp:265-270);
+        an int with one game, else an int32 array [n_games]."""
+        if self.store is None:
+            self._build(getattr(game, "n_games", 1))
+        idx = self.store.new_node(game.games).cpu().numpy()
+        return int(idx[0]) if self.n_games == 1 else idx
+
+    def expand(self, game):
+        """idx = new_node(game); child[idx][a] = new_node(game after action a) (agents/agent.py:136-145, agent.cpp:201-218)."""
+        if self.store is None:
+            self._build(getattr(game, "n_games", 1))
+        self.store.new_node(game.games, expand=True)
+
+    def remove_nodes(self):
+        """Collect everything unreachable from the root now (agents/agent.py:246-257); harvests replay tuples when online."""
+        self.store.remove_nodes()
+
     def get_value_and_variance(self, node=None):
-        """Root observation's (value, variance) (agents/agent.py:195-204); only node=None (the root) is supported."""
-        if node is not None:
-            raise NotImplementedError("only the root is addressable on the device store")
+        """(value, variance) of a node's observation (agents/agent.py:195-204); node=None is the root, else a node index
+        (one game) or an array of n_games indices."""
         s = self.store
         g = torch.arange(self.n_games, device=s.device)
-        root = s.t["gs"][:, st.GS["ROOT"]].long()
+        if node is None:
+            root = s.t["gs"][:, st.GS["ROOT"]].long()
+        else:
+            root = torch.as_tensor(np.atleast_1d(node), device=s.device).long().reshape(self.n_games)
         o = s.t["node_rec"][g, root, 29].long()
         vv = s.t["obs_stat"][g, o, 1:3].view(torch.float32).cpu().numpy()
         return (vv[0, 0], vv[0, 1]) if self.n_games == 1 else (vv[:, 0], vv[:, 1])

@@ -1333,6 +1333,55 @@ __global__ __launch_bounds__(64 * WPB) void k_update_root(tm_store S) {
     }
 }
 
+// TreeAgent's single calls, one game state per tree (agent.cpp:212-218 expand(buffer), 265-270 new_node(buffer);
+// agents/agent.py:90-145): idx = new_node(game), and for EXPAND the seven successors linked under it.  As in the
+// reference a collection may run at any of the pops; a game that is not reachable from the root does not survive it.
+template <bool EXPAND>
+__global__ __launch_bounds__(64 * WPB) void k_tree_node(tm_store S, const uint32_t* __restrict__ games,
+                                                        const uint8_t* __restrict__ mask, int32_t* __restrict__ out_idx) {
+    __shared__ WaveLds lds[WPB];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WPB + w;
+    if (g >= S.n_games) return;
+    if (mask && !mask[g]) { if (out_idx && lane == 0) out_idx[g] = -1; return; }
+    GP P = game_ptrs(S, g);
+    WaveLds& L = lds[w];
+    if (lane < GAME_DW) L.slots[0][lane] = games[(size_t)g * GAME_DW + lane];
+    wave_sync();
+    int idx, o;
+    wave_new_nodes(S, P, L, g, 1, lane, idx, o);
+    if (idx < 0) {
+        gc_wave(S, P, L, g, lane);
+        wave_new_nodes(S, P, L, g, 1, lane, idx, o);
+        if (idx < 0) { if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_POOL); idx = 0; }
+    }
+    idx = (int)rl_u32((uint32_t)idx, 0);
+    if (out_idx && lane == 0) out_idx[g] = idx;
+    if (!EXPAND) return;
+    __threadfence_block();
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint32_t self_sc = P.rec()[(size_t)idx * TM_REC_DW + TM_REC_SCORE];
+        const int gsv = P.gs()[lane];
+        uint32_t lh;
+        if (wave_expand(S, P, L, g, lane, idx, self_sc, lh, gsv)) break;
+        // the pool ran dry at one of the seven pops: the collection wave_expand asked for, now, then the expansion again
+        // (the successors already inserted are transposition hits; a second failure is TM_ERR_POOL inside wave_expand)
+        __threadfence_block();
+        gc_run(S, P, g, lane, -1);
+    }
+    if (lane == 0) { P.gs()[TM_GS_GC_RETRY] = 0; P.gs()[TM_GS_N_EXPAND] += 1; }
+}
+// TreeAgent.remove_nodes() (agent.cpp:337-..., agents/agent.py:246-257) as a call of its own
+__global__ __launch_bounds__(64 * WPB) void k_tree_gc(tm_store S, const uint8_t* __restrict__ mask) {
+    __shared__ WaveLds lds[WPB];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WPB + w;
+    if (g >= S.n_games) return;
+    if (mask && !mask[g]) return;
+    GP P = game_ptrs(S, g);
+    gc_wave(S, P, lds[w], g, lane);
+}
+
 // compute_stats + get_action (agents/agent.py:153-185; agent.cpp:149-172 for the all-C++ kinds)
 __global__ void k_root_stats(tm_store S, float* stats, int32_t* action) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1563,6 +1612,22 @@ int tm_env_info(const tm_store* s, int32_t* out, void* stream) {
 }
 int tm_update_root(const tm_store* s, void* stream) {
     hipLaunchKernelGGL(k_update_root, dim3((s->n_games + WPB - 1) / WPB), dim3(64 * WPB), 0, (hipStream_t)stream, *s);
+    return TM_LAUNCH_CHECK();
+}
+int tm_tree_new_node(const tm_store* s, const uint32_t* games, const uint8_t* mask, int32_t* out_idx, void* stream) {
+    if (!games) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tree_node<false>, dim3((s->n_games + WPB - 1) / WPB), dim3(64 * WPB), 0, (hipStream_t)stream, *s,
+                       games, mask, out_idx);
+    return TM_LAUNCH_CHECK();
+}
+int tm_tree_expand(const tm_store* s, const uint32_t* games, const uint8_t* mask, int32_t* out_idx, void* stream) {
+    if (!games) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tree_node<true>, dim3((s->n_games + WPB - 1) / WPB), dim3(64 * WPB), 0, (hipStream_t)stream, *s,
+                       games, mask, out_idx);
+    return TM_LAUNCH_CHECK();
+}
+int tm_tree_remove_nodes(const tm_store* s, const uint8_t* mask, void* stream) {
+    hipLaunchKernelGGL(k_tree_gc, dim3((s->n_games + WPB - 1) / WPB), dim3(64 * WPB), 0, (hipStream_t)stream, *s, mask);
     return TM_LAUNCH_CHECK();
 }
 int tm_sim_step(const tm_store* s, int flags, void* stream) {

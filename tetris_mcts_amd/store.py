@@ -114,6 +114,28 @@ class TreeStore:
     def update_root(self):
         _lib.check(self.L.tm_update_root(C.byref(self.s), _stream()), "tm_update_root")
 
+    # TreeAgent's single calls (agent.cpp:828-833; agents/agent.py:90-145,246-257), one game state per tree
+    def _mask(self, mask):
+        if mask is None:
+            return None, C.c_void_p(0)
+        m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        return m, _p(m)
+
+    def new_node(self, games, mask=None, expand=False):
+        """games: [G,16] packed games (device).  Returns the node index of every game's state (int32 [G], device);
+        expand=True also links its seven successors (TreeAgent.expand)."""
+        g = games.view(torch.int32).contiguous()
+        assert g.shape == (self.n_games, 16) and g.device.type == "cuda"
+        out = torch.empty(self.n_games, dtype=torch.int32, device=self.device)
+        keep, mp = self._mask(mask)
+        fn = self.L.tm_tree_expand if expand else self.L.tm_tree_new_node
+        _lib.check(fn(C.byref(self.s), _p(g), mp, _p(out), _stream()), "tm_tree_expand" if expand else "tm_tree_new_node")
+        return out
+
+    def remove_nodes(self, mask=None):
+        keep, mp = self._mask(mask)
+        _lib.check(self.L.tm_tree_remove_nodes(C.byref(self.s), mp, _stream()), "tm_tree_remove_nodes")
+
     def move_begin(self, sims):
         """Give every game a quota of `sims` more simulations (TreeAgent.play: mcts(root, sims), agents/agent.py:147-150)."""
         _lib.check(self.L.tm_move_begin(C.byref(self.s), int(sims), _stream()), "tm_move_begin")
