@@ -218,6 +218,21 @@ int tm_dist_transform(int n, int bins, const float *dist /* [n][bins] */, double
 int tm_dist_mean_variance(int n, int bins, const float *dist, double vmin, double vmax, double *out /* [n][2] */,
                           void *stream);
 
+/* agents/core_distributional.py, the numba kernels of the reference's unfinished distributional agent, batched (one tree
+ * or distribution per index): shift_distribution :12-37 (x[i] >= 0 in value units; mass reaching the top bin stays there),
+ * policy_dist :66-79 (child_nodes[B][7] with n_child[B] valid entries, node_stats[B][n_nodes][5] = visit, mean, score,
+ * variance, M2; returns the chosen child per tree), backup_trace_distributional :108-124 (updates node_stats and
+ * node_dist[B][n_nodes][bins] along trace[B][max_trace]; scratch[B][bins]).  `fastmath` numba code: held to a float
+ * tolerance (2e-6 relative), not to bit patterns.  Their mean_dist / mean_variance = tm_dist_mean_variance(vmin = 0,
+ * vmax = vmax - vmin). */
+int tm_distpy_shift(int n, int bins, const float *dist /* [n][bins] */, const double *x /* [n] */, double vmin, double vmax,
+                    float *out /* [n][bins] */, void *stream);
+int tm_distpy_policy(int n_trees, int n_nodes, const int32_t *child_nodes, const int32_t *n_child, const float *node_stats,
+                     const double *curr_reward /* [B] */, int32_t *out /* [B] */, void *stream);
+int tm_distpy_backup(int n_trees, int n_nodes, int bins, const int32_t *trace, const int32_t *trace_len, int max_trace,
+                     float *node_stats, float *node_dist, const double *r /* [B] */, const float *leaf_dist /* [B][bins] */,
+                     double vmin, double vmax, float *scratch, void *stream);
+
 /* value network forward (model/model_vv.py:13-52; Model_VV.inference 210-217): states int8 [n][200] -> v[n], var[n].
  * params: 478342 floats in PyTorch state_dict layouts (order as in oracle/valuenet_oracle.c).
  * tm_valuenet_prepare re-lays the conv2/conv3/fc1 weights into MFMA operand streams (call after every weight

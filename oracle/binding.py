@@ -91,6 +91,9 @@ def lib():
         L.orc_transform_distribution.argtypes = [vp, i32, f64, f64, f64, f64, vp]
         L.orc_mean_dist.restype, L.orc_mean_dist.argtypes = f64, [vp, i32, f64, f64]
         L.orc_mean_variance_dist.argtypes = [vp, i32, f64, f64, vp]
+        L.orc_distpy_shift.argtypes = [vp, i32, f64, f64, f64, vp]
+        L.orc_distpy_policy.restype, L.orc_distpy_policy.argtypes = i32, [vp, i32, vp, f64]
+        L.orc_distpy_backup.argtypes = [vp, i32, vp, vp, i32, f64, vp, f64, f64, vp]
         _lib = L
     return _lib
 

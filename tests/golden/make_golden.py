@@ -518,6 +518,76 @@ def gen_treeagent():
         json.dump(out, f)
 
 
+def gen_distpy():
+    """ref_distpy.npz: the reference's numba kernels of agents/core_distributional.py (shift_distribution :12-37,
+    policy_dist :66-79, backup_trace_distributional :108-124) run as plain Python (numba shimmed away; they are `fastmath`
+    numba code, so their compiled bit patterns are not defined - the fixtures are held to a float tolerance).  policy_dist
+    cases are kept only when the winning bound leads by a clear margin."""
+    ref_shims.install()
+    from agents import core_distributional as cd
+    from agents.special import norm_quantile
+    rng = np.random.default_rng(77)
+    out = {}
+    # shift_distribution: shifts >= 0 (the only ones backup produces: a leaf's score is never below an ancestor's)
+    n = 0
+    for bins, vmax in ((50, 5000.0), (31, 310.0), (64, 100.0)):
+        for x in (0.0, 1.0, 99.5, 100.0, 250.25, 1234.0, vmax - 1.0, vmax + 500.0):
+            d = rng.random(bins).astype(np.float32)
+            d /= d.sum()
+            r = cd.shift_distribution(d, x, 0.0, vmax)
+            out.update({"s_dist_%d" % n: d, "s_x_%d" % n: x, "s_vmax_%d" % n: vmax, "s_out_%d" % n: np.asarray(r, np.float32)})
+            n += 1
+    out["s_n"] = n
+    # policy_dist
+    n = 0
+    while n < 40:
+        n_nodes = 30
+        ns = np.zeros((n_nodes, 5), np.float32)
+        ns[:, 0] = rng.integers(1, 60, n_nodes)
+        ns[:, 1] = rng.random(n_nodes) * 400
+        ns[:, 2] = rng.integers(0, 30, n_nodes) * 10
+        ns[:, 3] = rng.random(n_nodes) * 2000
+        nd = rng.random((n_nodes, 50)).astype(np.float32)
+        nc = int(rng.integers(1, 8))
+        cn = [int(c) for c in rng.choice(np.arange(1, n_nodes), nc, replace=False)]
+        cur = float(ns[0, 2])
+        got = int(cd.policy_dist(cn, ns, nd, cur, 0.0, 5000.0))
+        tot = float(sum(float(ns[c, 0]) for c in cn))
+        q = sorted(float(ns[c, 1]) + float(ns[c, 2]) - cur + norm_quantile(tot) * np.sqrt(float(ns[c, 3]) / (float(ns[c, 0]) + 1e-3))
+                   for c in cn)
+        if len(q) > 1 and q[-1] - q[-2] < 1e-2:
+            continue
+        out.update({"p_stats_%d" % n: ns, "p_nodes_%d" % n: np.asarray(cn, np.int32), "p_cur_%d" % n: cur, "p_out_%d" % n: got})
+        n += 1
+    out["p_n"] = n
+    # backup_trace_distributional
+    n = 0
+    for bins, vmax, tl in ((50, 5000.0, 9), (50, 5000.0, 1), (32, 640.0, 20), (64, 2000.0, 14)):
+        for rep in range(3):
+            n_nodes = 40
+            ns = np.zeros((n_nodes, 5), np.float32)
+            ns[:, 0] = rng.integers(0, 25, n_nodes)
+            ns[:, 1] = rng.random(n_nodes) * vmax * 0.3
+            ns[:, 2] = rng.integers(0, 20, n_nodes) * 10
+            ns[:, 4] = rng.random(n_nodes) * 3000 * (ns[:, 0] > 0)
+            ns[:, 3] = np.where(ns[:, 0] > 1, ns[:, 4] / np.maximum(ns[:, 0] - 1, 1), 0)
+            nd = rng.random((n_nodes, bins)).astype(np.float32)
+            nd /= nd.sum(1, keepdims=True)
+            nd[ns[:, 0] == 0] = 0
+            trace = rng.choice(np.arange(1, n_nodes), tl, replace=False).astype(np.int32)
+            d = rng.random(bins).astype(np.float32)
+            d /= d.sum()
+            r = float(ns[trace, 2].max() + 10 * rng.integers(0, 8))
+            ns_in, nd_in = ns.copy(), nd.copy()
+            cd.backup_trace_distributional(trace, ns, nd, r, d, 0.0, vmax)
+            out.update({"b_stats_in_%d" % n: ns_in, "b_dist_in_%d" % n: nd_in, "b_trace_%d" % n: trace, "b_r_%d" % n: r,
+                        "b_leaf_%d" % n: d, "b_vmax_%d" % n: vmax, "b_stats_out_%d" % n: ns, "b_dist_out_%d" % n: nd})
+            n += 1
+    out["b_n"] = n
+    np.savez_compressed(os.path.join(OUT, "ref_distpy.npz"), **out)
+    print("ref_distpy.npz: %d shift, %d policy, %d backup cases" % (out["s_n"], out["p_n"], out["b_n"]))
+
+
 def gen_dist():
     """ref_dist.npz: the reference's distribution helpers (core.h:387-449, compiled through oracle/ref_dist_shim.cpp) on
     seeded categorical distributions.  Only cases in which the reference's write to result[bins] adds exactly 0 or does not
@@ -669,7 +739,7 @@ def gen_training():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training", "vanillac", "dist", "distnet", "treeagent"]
+    which = sys.argv[1:] or ["uct", "valuenet", "agents", "cppagent", "mixture", "vanilla", "online", "online_py", "agents_env", "training", "vanillac", "dist", "distnet", "treeagent", "distpy"]
     params = None
     if "uct" in which:
         gen_uct()
@@ -693,6 +763,8 @@ if __name__ == "__main__":
         gen_vanillac()
     if "treeagent" in which:
         gen_treeagent()
+    if "distpy" in which:
+        gen_distpy()
     if "dist" in which:
         gen_dist()
     if "distnet" in which:

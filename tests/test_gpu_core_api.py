@@ -187,3 +187,69 @@ def test_distribution_helpers_match_the_reference(golden_dir):
         for j, i in enumerate(idx):
             assert out[j].cpu().numpy().tobytes() == g["out_%d" % i].astype(np.float32).tobytes(), i
             assert mv[j].cpu().numpy().tobytes() == g["mv_%d" % i].astype(np.float64).tobytes(), i
+
+
+def test_distributional_numba_kernels_match_the_reference_functions(oracle, golden_dir):
+    """tm_distpy_shift / tm_distpy_policy / tm_distpy_backup vs a pure-Python run of agents/core_distributional.py
+    (ref_distpy.npz; `fastmath` numba code: float tolerance) and vs the oracle restatement (same arithmetic: bit for bit
+    where no libm call is involved)."""
+    import torch
+    from tetris_mcts_amd import _lib
+    from tetris_mcts_amd.store import _p, _stream
+    from test_oracle_dist import ATOL, RTOL, distpy_cases
+    L, OL = _lib.lib(), oracle.lib()
+    cuda = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    # shift_distribution, batched by shape
+    groups = {}
+    for c in distpy_cases(golden_dir, "s", ("dist", "x", "vmax", "out")):
+        groups.setdefault((len(c["dist"]), float(c["vmax"])), []).append(c)
+    n = 0
+    for (bins, vmax), cs in groups.items():
+        d = cuda(np.stack([c["dist"] for c in cs]).astype(np.float32))
+        x = cuda(np.array([float(c["x"]) for c in cs], np.float64))
+        out = torch.zeros_like(d)
+        _lib.check(L.tm_distpy_shift(len(cs), bins, _p(d), _p(x), 0.0, vmax, _p(out), _stream()), "tm_distpy_shift")
+        got = out.cpu().numpy()
+        for i, c in enumerate(cs):
+            assert np.allclose(got[i], c["out"], rtol=RTOL, atol=ATOL), (bins, i)
+            want = np.zeros(bins, np.float32)
+            src = np.ascontiguousarray(c["dist"], np.float32)
+            OL.orc_distpy_shift(oracle.ptr(src), bins, float(c["x"]), 0.0, vmax, oracle.ptr(want))
+            assert got[i].tobytes() == want.tobytes(), (bins, i)
+            n += 1
+    assert n == 24
+    # policy_dist: all 40 trees in one call
+    cs = list(distpy_cases(golden_dir, "p", ("stats", "nodes", "cur", "out")))
+    N = cs[0]["stats"].shape[0]
+    cn = np.zeros((len(cs), 7), np.int32)
+    for i, c in enumerate(cs):
+        cn[i, :len(c["nodes"])] = c["nodes"]
+    out = torch.zeros(len(cs), dtype=torch.int32, device="cuda")
+    args = [cuda(cn), cuda(np.array([len(c["nodes"]) for c in cs], np.int32)),
+            cuda(np.stack([c["stats"] for c in cs]).astype(np.float32)), cuda(np.array([float(c["cur"]) for c in cs], np.float64))]
+    _lib.check(L.tm_distpy_policy(len(cs), N, *[_p(a) for a in args], _p(out), _stream()), "tm_distpy_policy")
+    assert out.cpu().numpy().tolist() == [int(c["out"]) for c in cs]
+    # backup_trace_distributional, batched by shape
+    groups = {}
+    for c in distpy_cases(golden_dir, "b", ("stats_in", "dist_in", "trace", "r", "leaf", "vmax", "stats_out", "dist_out")):
+        groups.setdefault((c["dist_in"].shape, float(c["vmax"]), len(c["trace"])), []).append(c)
+    n = 0
+    for ((N, bins), vmax, tl), cs in groups.items():
+        B = len(cs)
+        ns, nd = cuda(np.stack([c["stats_in"] for c in cs])), cuda(np.stack([c["dist_in"] for c in cs]))
+        tr, tlen = cuda(np.stack([c["trace"] for c in cs]).astype(np.int32)), cuda(np.full(B, tl, np.int32))
+        r, leaf = cuda(np.array([float(c["r"]) for c in cs], np.float64)), cuda(np.stack([c["leaf"] for c in cs]).astype(np.float32))
+        scratch = torch.zeros(B, bins, device="cuda")
+        _lib.check(L.tm_distpy_backup(B, N, bins, _p(tr), _p(tlen), tl, _p(ns), _p(nd), _p(r), _p(leaf), 0.0, vmax, _p(scratch),
+                                      _stream()), "tm_distpy_backup")
+        gs, gd = ns.cpu().numpy(), nd.cpu().numpy()
+        for i, c in enumerate(cs):
+            assert np.allclose(gs[i], c["stats_out"], rtol=1e-5, atol=1e-4), (N, bins, i)
+            assert np.allclose(gd[i], c["dist_out"], rtol=RTOL, atol=ATOL), (N, bins, i)
+            os_, od = c["stats_in"].copy(), c["dist_in"].copy()
+            t_, l_, sc = np.ascontiguousarray(c["trace"], np.int32), np.ascontiguousarray(c["leaf"], np.float32), np.zeros(bins, np.float32)
+            OL.orc_distpy_backup(oracle.ptr(t_), tl, oracle.ptr(os_), oracle.ptr(od), bins, float(c["r"]), oracle.ptr(l_), 0.0, vmax,
+                                 oracle.ptr(sc))
+            assert gs[i].tobytes() == os_.tobytes() and gd[i].tobytes() == od.tobytes(), (N, bins, i)
+            n += 1
+    assert n == 12

@@ -54,3 +54,54 @@ def test_distributional_net_matches_the_reference(golden_dir):
         lp = net.log_prob(torch.from_numpy(g["x"])).numpy()
     assert y.tobytes() == g["y"].tobytes() and lp.tobytes() == g["lp"].tobytes()
     assert np.allclose(y.sum(1), 1.0, atol=1e-6)
+
+
+# ---- agents/core_distributional.py (numba, fastmath): float tolerance, not bit patterns ----
+RTOL, ATOL = 2e-6, 1e-7      # pure-Python run of the reference (float32 scalars under NumPy 2) vs numba's typing in double
+
+
+def distpy_cases(golden_dir, prefix, keys):
+    g = np.load(os.path.join(golden_dir, "ref_distpy.npz"))
+    for i in range(int(g[prefix + "_n"])):
+        yield {k: g["%s_%s_%d" % (prefix, k, i)] for k in keys}
+
+
+def test_distpy_shift_matches_the_reference_function(oracle, golden_dir):
+    L, n = oracle.lib(), 0
+    for c in distpy_cases(golden_dir, "s", ("dist", "x", "vmax", "out")):
+        d = np.ascontiguousarray(c["dist"], np.float32)
+        out = np.zeros(len(d), np.float32)
+        L.orc_distpy_shift(oracle.ptr(d), len(d), float(c["x"]), 0.0, float(c["vmax"]), oracle.ptr(out))
+        assert np.allclose(out, c["out"], rtol=RTOL, atol=ATOL), (n, np.abs(out - c["out"]).max())
+        assert abs(float(out.sum()) - float(d.sum())) < 1e-5      # a shift moves mass, it does not lose any
+        n += 1
+    assert n == 24
+
+
+def test_distpy_policy_matches_the_reference_function(oracle, golden_dir):
+    L, n = oracle.lib(), 0
+    for c in distpy_cases(golden_dir, "p", ("stats", "nodes", "cur", "out")):
+        ns = np.ascontiguousarray(c["stats"], np.float32)
+        cn = np.ascontiguousarray(c["nodes"], np.int32)
+        assert L.orc_distpy_policy(oracle.ptr(cn), len(cn), oracle.ptr(ns), float(c["cur"])) == int(c["out"]), n
+        n += 1
+    assert n == 40
+
+
+def test_distpy_backup_matches_the_reference_function(oracle, golden_dir):
+    L, n = oracle.lib(), 0
+    for c in distpy_cases(golden_dir, "b", ("stats_in", "dist_in", "trace", "r", "leaf", "vmax", "stats_out", "dist_out")):
+        ns = np.ascontiguousarray(c["stats_in"], np.float32).copy()
+        nd = np.ascontiguousarray(c["dist_in"], np.float32).copy()
+        tr = np.ascontiguousarray(c["trace"], np.int32)
+        leaf = np.ascontiguousarray(c["leaf"], np.float32)
+        bins = nd.shape[1]
+        scratch = np.zeros(bins, np.float32)
+        L.orc_distpy_backup(oracle.ptr(tr), len(tr), oracle.ptr(ns), oracle.ptr(nd), bins, float(c["r"]), oracle.ptr(leaf),
+                            0.0, float(c["vmax"]), oracle.ptr(scratch))
+        assert np.allclose(ns, c["stats_out"], rtol=1e-5, atol=1e-4), (n, np.abs(ns - c["stats_out"]).max())
+        assert np.allclose(nd, c["dist_out"], rtol=RTOL, atol=ATOL), (n, np.abs(nd - c["dist_out"]).max())
+        untouched = np.setdiff1d(np.arange(len(ns)), tr)
+        assert ns[untouched].tobytes() == c["stats_in"][untouched].tobytes()
+        n += 1
+    assert n == 12

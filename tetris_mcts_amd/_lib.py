@@ -55,6 +55,9 @@ SYMBOLS = {
     "tm_valuenet_forward_requests": [vp, vp, C.POINTER(TmStore), vp, vp],
     "tm_dist_transform": [i32, i32, vp, f64, f64, vp, f64, vp, vp],
     "tm_dist_mean_variance": [i32, i32, vp, f64, f64, vp, vp],
+    "tm_distpy_shift": [i32, i32, vp, vp, f64, f64, vp, vp],
+    "tm_distpy_policy": [i32, i32, vp, vp, vp, vp, vp, vp],
+    "tm_distpy_backup": [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, f64, f64, vp, vp],
     "tm_store_slice": [C.POINTER(TmStore), i32, i32, C.POINTER(TmStore)],
     "tm_search_create": [C.POINTER(vp), C.POINTER(TmStore), i32, i32],
     "tm_search_run": [vp, i32, vp, vp, vp, vp],

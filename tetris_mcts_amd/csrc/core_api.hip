@@ -269,6 +269,101 @@ __global__ void k_dist_mean_variance(int n, int bins, const float* __restrict__ 
     out[2 * i + 1] = m2 - mean * mean;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// agents/core_distributional.py (the numba kernels of the reference's unfinished distributional agent): shift_distribution
+// :12-37, policy_dist :66-79, backup_trace_distributional :108-124, batched over trees, one lane per tree.  The reference
+// code is `fastmath` numba: no bit pattern is defined, the arithmetic here follows numba's typing (float32 arrays,
+// float64 scalars; see oracle/dist_oracle.c) and is held to a float tolerance against a pure-Python run of the reference.
+// ---------------------------------------------------------------------------------------------------
+__device__ inline int py_index(int i, int n) { return i < 0 ? i + n : i; }   // Python / numba wraparound indexing
+__device__ inline void distpy_shift(const float* d, int bins, double x, double vmin, double vmax, float* r) {
+    const double delta = (vmax - vmin) / bins;
+    for (int b = 0; b < bins; ++b) r[b] = 0.0f;
+    const double bin_shift = x / delta;
+    const double fraction = bin_shift - floor(bin_shift);
+    for (int b = 0; b < bins; ++b) {
+        int b_lb = (int)(b + bin_shift);
+        if (b_lb >= bins) b_lb = bins - 1;
+        const int b_ub = (b_lb + 1 >= bins) ? bins - 1 : b_lb + 1;
+        const int lo = py_index(b_lb, bins), hi = py_index(b_ub, bins);
+        if (lo >= 0) r[lo] = (float)((double)r[lo] + (double)d[b] * (1 - fraction));
+        if (hi >= 0) r[hi] = (float)((double)r[hi] + (double)d[b] * fraction);
+    }
+}
+__global__ void k_distpy_shift(int n, int bins, const float* __restrict__ dist, const double* __restrict__ x, double vmin,
+                               double vmax, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    distpy_shift(dist + (size_t)i * bins, bins, x[i], vmin, vmax, out + (size_t)i * bins);
+}
+__global__ void k_distpy_policy(int B, int N, const int32_t* __restrict__ child_nodes, const int32_t* __restrict__ n_child,
+                                const float* __restrict__ node_stats, const double* __restrict__ curr_reward,
+                                int32_t* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B) return;
+    const int32_t* cn = child_nodes + (size_t)t * 7;
+    const float* st = node_stats + (size_t)t * N * 5;
+    const int nc = min(max(n_child[t], 0), 7);
+    if (nc == 0) { out[t] = 0; return; }
+    const double eps = 1e-3;
+    double n = 0;
+    float s0[7], s1[7];
+    for (int i = 0; i < nc; ++i) {
+        const float* ns = st + (size_t)cn[i] * 5;
+        n += ns[0];
+        const float a = ns[1] + ns[2];
+        s0[i] = (float)((double)a - curr_reward[t]);
+        s1[i] = (float)((double)ns[3] / ((double)ns[0] + eps));
+    }
+    const double alpha = 1 - 1 / n;
+    const double coeff = 10 * log(1 - log(-log(alpha) / log(2.0)) / log(22.0)) / log(41.0);
+    int best = 0;
+    double best_q = 0;
+    for (int i = 0; i < nc; ++i) {
+        const double q = (double)s0[i] + coeff * (double)sqrtf(s1[i]);
+        if (i == 0) { best_q = q; continue; }
+        if (best_q != best_q) break;                       // np.argmax: the first NaN wins
+        if (q != q || q > best_q) { best_q = q; best = i; }
+    }
+    out[t] = cn[best];
+}
+__global__ void k_distpy_backup(int B, int N, int bins, const int32_t* __restrict__ trace, const int32_t* __restrict__ trace_len,
+                                int max_trace, float* __restrict__ node_stats, float* __restrict__ node_dist,
+                                const double* __restrict__ r, const float* __restrict__ leaf_dist, double vmin, double vmax,
+                                float* __restrict__ scratch) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B) return;
+    const float* dist = leaf_dist + (size_t)t * bins;
+    float* sc = scratch + (size_t)t * bins;
+    const double delta = (vmax - vmin) / bins;
+    double mean = 0;
+    for (int b = 0; b < bins; ++b) mean += (double)dist[b] * ((b + 0.5) * delta);
+    const int len = trace_len[t];
+    for (int k = 0; k < len; ++k) {
+        const int idx = trace[(size_t)t * max_trace + k];
+        float* ns = node_stats + ((size_t)t * N + idx) * 5;
+        float* nd = node_dist + ((size_t)t * N + idx) * bins;
+        const double _r = r[t] - (double)ns[2];
+        distpy_shift(dist, bins, _r, vmin, vmax, sc);
+        const float n0 = ns[0];
+        for (int b = 0; b < bins; ++b) {
+            const float m = nd[b] * n0;
+            const float u = m + sc[b];
+            nd[b] = (float)((double)u / ((double)n0 + 1.0));
+        }
+        const double x = mean + _r;
+        const float n1 = n0 + 1.0f;
+        ns[0] = n1;
+        const double d1 = x - (double)ns[1];
+        const float v = (float)((double)ns[1] + d1 / (double)n1);
+        ns[1] = v;
+        const double d2 = x - (double)v;
+        const float m2 = (float)((double)ns[4] + d1 * d2);
+        ns[4] = m2;
+        if (n1 > 1.0f) ns[3] = (float)((double)m2 / ((double)n1 - 1.0));
+    }
+}
+
 extern "C" {
 int tm_core_select_trace_obs(int B, int N, const int32_t* roots, const int32_t* child, const int32_t* visit,
                              const float* value, const float* variance, const float* score, const int32_t* n_to_o,
@@ -309,6 +404,26 @@ int tm_dist_transform(int n, int bins, const float* dist, double vmin, double vm
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_dist_transform, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, bins, dist, vmin, vmax,
                        shift, scale, out);
+    return (int)hipGetLastError();
+}
+int tm_distpy_shift(int n, int bins, const float* dist, const double* x, double vmin, double vmax, float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_distpy_shift, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, bins, dist, x, vmin, vmax, out);
+    return (int)hipGetLastError();
+}
+int tm_distpy_policy(int B, int n_nodes, const int32_t* child_nodes, const int32_t* n_child, const float* node_stats,
+                     const double* curr_reward, int32_t* out, void* stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_distpy_policy, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, n_nodes, child_nodes, n_child,
+                       node_stats, curr_reward, out);
+    return (int)hipGetLastError();
+}
+int tm_distpy_backup(int B, int n_nodes, int bins, const int32_t* trace, const int32_t* trace_len, int max_trace,
+                     float* node_stats, float* node_dist, const double* r, const float* leaf_dist, double vmin, double vmax,
+                     float* scratch, void* stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_distpy_backup, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, n_nodes, bins, trace,
+                       trace_len, max_trace, node_stats, node_dist, r, leaf_dist, vmin, vmax, scratch);
     return (int)hipGetLastError();
 }
 int tm_dist_mean_variance(int n, int bins, const float* dist, double vmin, double vmax, double* out, void* stream) {
