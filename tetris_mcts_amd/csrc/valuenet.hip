@@ -471,38 +471,6 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     }
 }
 
-
-// fc_out (256 -> 2) + sigmoid + affine for 32 states per workgroup: hidden rows staged in LDS, one lane per
-// (state, output) walks the 256-term fma chain in order.
-__global__ __launch_bounds__(64) void k_vn_fcout(const float* __restrict__ h, int hstride, const float* __restrict__ P,
-                                                 float* __restrict__ v, float* __restrict__ var, int n) {
-    __shared__ float hs[32 * 257];
-    __shared__ float ws[512];
-    const int t = threadIdx.x, s0 = blockIdx.x * 32;
-    for (int i = t; i < 512; i += 64) ws[i] = P[OFF_FOW + i];
-    for (int e = t; e < 32 * 64; e += 64) {
-        int row = e >> 6, c4 = (e & 63) * 4;
-        float4 x = (s0 + row < n) ? *reinterpret_cast<const float4*>(h + (size_t)(s0 + row) * hstride + c4)
-                                  : make_float4(0, 0, 0, 0);
-        float* d = &hs[row * 257 + c4];
-        d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-    }
-    __syncthreads();
-    const int j = t & 31, o = t >> 5;
-    float acc = P[OFF_FOB + o];
-    const float* x = &hs[j * 257];
-    const float* wr = &ws[o * 256];
-#pragma unroll 8
-    for (int i = 0; i < HID; ++i) acc = fmaf(x[i], wr[i], acc);
-    if (s0 + j < n) {
-        double e = tm_exp(-(double)acc);
-        float sg = (float)(1.0 / (1.0 + e));
-        float tt = sg * P[OFF_UB + o];
-        float r = tt + P[OFF_LB + o];
-        if (o == 0) v[s0 + j] = r; else var[s0 + j] = r;
-    }
-}
-
 }  // namespace tmcts_vn
 
 using namespace tmcts_vn;
