@@ -818,6 +818,16 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
 #else
 #define TM_WALK_PROF(SC, RN)
 #endif
+#ifdef TM_EXP_NQ_CONST   /* timing experiment only (wrong results): what the table lookup's latency costs a level */
+#define TM_NQ_LOOKUP(CB, N) CB = 0x3f800000 | ((N) & 0xffff);
+#define TM_NQ_WAIT(CB, V)
+#elif defined(TM_NQ_SPLIT)   /* the table word is awaited after the part of the bound that does not need it */
+#define TM_NQ_LOOKUP(CB, N) asm volatile("s_load_dword %0, %1, %2" : "=s"(CB) : "s"(nq_base), "s"((N) << 2));
+#define TM_NQ_WAIT(CB, V) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(CB), "+v"(V));
+#else
+#define TM_NQ_LOOKUP(CB, N) asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(CB) : "s"(nq_base), "s"((N) << 2));
+#define TM_NQ_WAIT(CB, V)
+#endif
     // three record register sets and two statistics sets rotate through the roles (current node, predicted child,
     // predicted grandchild) / (this level, next level): the loop body is instantiated six times instead of moving
     // eleven registers per level.  p0..p2 = predicted child (piece 7, word 0) of the node held in r0..r2.
@@ -868,10 +878,11 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
                 cbits = __builtin_amdgcn_readfirstlane(__float_as_int(norm_quantile_dev((double)n)));                   \
                 nq_fallback += 1;                                                                                       \
             } else {                                                                                                    \
-                asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(cbits) : "s"(nq_base), "s"(n << 2)); \
+                TM_NQ_LOOKUP(cbits, n)                                                                                  \
             }                                                                                                           \
             const float t1 = __uint_as_float(SC.y) + __uint_as_float(RC.z);                                             \
-            const float val = t1 - __uint_as_float(RC.w);                                                               \
+            float val = t1 - __uint_as_float(RC.w);                                                                     \
+            TM_NQ_WAIT(cbits, val)                                                                                      \
             const float prod = __int_as_float(cbits) * __uint_as_float(SC.w);                                           \
             const float q = (val + prod) + 0.0f;         /* -0 becomes +0 (the float compare treats them as equal) */   \
             /* first-max argmax with the reference's scan semantics (max_q = q_0; i >= 1 replaces only if q_i > max_q): \
@@ -907,6 +918,8 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     }
 #undef TM_WALK_LEVEL
 #undef TM_WALK_PROF
+#undef TM_NQ_LOOKUP
+#undef TM_NQ_WAIT
     idx = cur_node;
     wave_sync();
     // piece 7 of the node the walk ended at = the last trace entry (on a trace overflow the node is not recorded: it is
