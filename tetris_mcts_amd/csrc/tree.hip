@@ -263,6 +263,14 @@ __device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, u
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane);
 __device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, int lane, long long budget);
 
+#ifdef TM_PROF_EXPAND   /* instrumented build: cycles since the start of the expansion at probe i -> control word 48 + i */
+#define TM_XP_START(L) { const long long t_ = __builtin_readcyclecounter(); (L).misc[62] = (uint32_t)t_; }
+#define TM_XP(L, P, i) { if (lane == 0) (P).gs()[48 + (i)] = (int)((uint32_t)__builtin_readcyclecounter() - (L).misc[62]); }
+#else
+#define TM_XP_START(L) {}
+#define TM_XP(L, P, i) {}
+#endif
+
 // `gsv`: the wave's snapshot of the game's control block (word i in lane i), valid when nothing in this launch has changed
 // the free-list words yet (the expansion's first attempt); has_gsv = false: read them from memory (sequential retries,
 // update_root).
@@ -290,7 +298,9 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     int found = 0;
     uint32_t ins = 0;
     bool full = false;
+    if (n == 7) TM_XP(L, P, 2)
     if (uniq) found = table_find(P.ntab(), mask, h, my, P.game(), GAME_DW, ins, full);
+    if (n == 7) TM_XP(L, P, 3)
     bool isnew = uniq && !found && !full;
     uint64_t need = __ballot(isnew);
     int cnt = __popcll(need);
@@ -319,6 +329,7 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         if (lane == 0) { P.gs()[TM_GS_NFREE_NODE] = nfree - cnt; if (lo < low_seen) P.gs()[TM_GS_LOW_NODE] = lo; }
     }
     table_insert_seq(P.ntab(), mask, need, n, lane, h, ins, idx, L.misc);
+    if (n == 7) TM_XP(L, P, 4)
     // 3. observations of the new nodes (agents/agent.py:112-128)
     uint32_t* ok = L.okeys[act ? lane : 0];
     uint64_t ho = 0;
@@ -334,7 +345,9 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     int ofound = 0;
     uint32_t oins = 0;
     bool ofull = false;
+    if (n == 7) TM_XP(L, P, 5)
     if (ouniq) ofound = table_find(P.otab(), mask, ho, ok, P.okey(), OBS_DW, oins, ofull);
+    if (n == 7) TM_XP(L, P, 6)
     bool onew = ouniq && !ofound && !ofull;
     uint64_t oneed = __ballot(onew);
     int ocnt = __popcll(oneed);
@@ -352,6 +365,7 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         if (lane == 0) { P.gs()[TM_GS_NFREE_OBS] = onfree - ocnt; if (lo < olow_seen) P.gs()[TM_GS_LOW_OBS] = lo; }
     }
     table_insert_seq(P.otab(), mask, oneed, n, lane, ho, oins, o, L.misc + 8);
+    if (n == 7) TM_XP(L, P, 7)
     if (onew) {
         uint4* dst = reinterpret_cast<uint4*>(P.okey() + (size_t)o * OBS_DW);
         dst[0] = make_uint4(ok[0], ok[1], ok[2], ok[3]);
@@ -401,10 +415,12 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
                                    uint32_t self_sc /* float bits of the leaf's own score */, uint32_t& hdr_out, int gsv) {
+    TM_XP_START(L)
     if (lane < GAME_DW) L.slots[7][lane] = P.game()[(size_t)leaf * GAME_DW + lane];
     wave_sync();
     for (int t = lane; t < 7 * GAME_DW; t += 64) L.slots[t >> 4][t & 15] = L.slots[7][t & 15];
     wave_sync();
+    TM_XP(L, P, 0)
     EngCfg cfg{S.app, S.scoring, S.randomizer};
     const int drop = hard_drop_rows(L.slots[7], lane);       // for the successor of action 3: 21 lanes instead of a 20-step loop in one
     if (lane < 7) {
@@ -414,8 +430,10 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
         store_fields(L.slots[lane], p);
     }
     wave_sync();
+    TM_XP(L, P, 1)
     int idx, o;
     wave_new_nodes(S, P, L, g, 7, lane, idx, o, true, gsv);
+    TM_XP(L, P, 8)
     if (idx < 0) {
         // slow path: sequential new_node with a GC at the exhausting pop (rare: once per ~50 moves)
         int out_idx = 0, out_o = 0;
@@ -497,6 +515,7 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
         if (lane == 0) { L.misc[56] = hdr; r[TM_REC_HDR] = hdr; }
     }
     wave_sync();
+    TM_XP(L, P, 9)
     hdr_out = L.misc[56];
     return true;
 }
