@@ -507,11 +507,7 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
         wave_sync();
         if (leader) {
             // (child, observation, child score, own score): the walk's lane group for this slot needs nothing else
-#ifdef TM_WALK2
-            reinterpret_cast<uint4*>(r)[slot] = make_uint4(best_c, my_o, __float_as_uint(best_s), slot == 0 ? 0u : self_sc);
-#else
             reinterpret_cast<uint4*>(r)[slot] = make_uint4(best_c, my_o, __float_as_uint(best_s), self_sc);
-#endif
             L.misc[16 + slot] = best_c;                 // slot-ordered copies for the evaluation requests
             L.misc[24 + slot] = my_o;
             L.misc[32 + slot] = __float_as_uint(best_s);
@@ -851,113 +847,6 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
 #define TM_NQ_LOOKUP(CB, N) asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(CB) : "s"(nq_base), "s"((N) << 2));
 #define TM_NQ_WAIT(CB, V)
 #endif
-#ifdef TM_WALK2
-    // EXPERIMENTAL (not the default build): two levels per memory round trip.  A record also
-    // holds the predicted GRANDchild (piece 0, word 3: the child the last walk took at the predicted child), so the record
-    // of level j+4 is requested as soon as the record of level j+2 is here, and the statistics of level j+2's children with
-    // it: every load is issued two levels before its use, and a level waits only for loads that are two levels old.
-    // Six record sets r0..r5 (node ids q0..q5) and three statistics sets s0..s2 rotate through six instances of the body:
-    // level j reads r[j] / s[j%3], assumes r[j+1] is its child, uses r[j+2] to issue s[(j+2)%3] and r[j+4].
-    // A selection that differs from the assumed child rewrites the two predictions it contradicts and restarts the
-    // pipeline at the selected child (two round trips).  Results never depend on predictions.
-    uint4 r0, r1, r2, r3, r4 = make_uint4(0, 0, 0, 0), r5 = r4, s0, s1, s2 = r4;
-    uint32_t q0, q1, q2, q3, q4 = 0, q5 = 0;
-    uint32_t prev_node = 0, prev_pp = 0;
-    int cur_node = idx;
-    // (re)start at node C: A = its record, B / C_ = predicted child / grandchild, D = B's predicted grandchild
-#define TM_WALK_START(C, RA, QA, SA, RB, QB, RC_, QC, SB, RD, QD)                                                       \
-    {                                                                                                                   \
-        QA = (C);                                                                                                       \
-        RA = buf_ld16(rec_rs, QA * (TM_REC_DW * 4u) + grp16);                                                           \
-        QB = rl_u32(RA.x, 56);                                                                                          \
-        QC = rl_u32(RA.w, 0);                                                                                           \
-        SA = buf_ld16(stat_rs, RA.y * 16u);                                                                             \
-        RB = buf_ld16(rec_rs, QB * (TM_REC_DW * 4u) + grp16);                                                           \
-        RC_ = buf_ld16(rec_rs, QC * (TM_REC_DW * 4u) + grp16);                                                          \
-        QD = rl_u32(RB.w, 0);                                                                                           \
-        SB = buf_ld16(stat_rs, RB.y * 16u);                                                                             \
-        RD = buf_ld16(rec_rs, QD * (TM_REC_DW * 4u) + grp16);                                                           \
-    }
-    TM_WALK_START((uint32_t)idx, r0, q0, s0, r1, q1, r2, q2, s1, r3, q3)
-#define TM_WALK_LEVEL(RC, QC, SC, R1, Q1, S1, R2, Q2, S2, R3, Q3, R4, Q4)                                               \
-    {                                                                                                                   \
-        if (__builtin_expect((len & (TRACE_LDS - 1)) == 0, 0)) {                                                        \
-            if (len != 0) {      /* the LDS trace buffer is full */                                                     \
-                if (len >= max_trace) { overflow = true; break; }                                                       \
-                wave_sync(); flush_trace(len); wave_sync();                                                             \
-                if (lane == 56) tp = &L.tbuf[0];                                                                        \
-            }                                                                                                           \
-        }                                                                                                               \
-        *tp = RC;                /* lane 56 holds piece 7: (predicted child, own observation, own score, header) */     \
-        tp += tinc;                                                                                                     \
-        len += 1;                                                                                                       \
-        cur_node = (int)QC;                                                                                             \
-        const uint64_t onm = __builtin_amdgcn_ballot_w64(RC.x != 0u) & lanes_lt56;                                      \
-        if (onm == 0ull) break;                       /* no children: a leaf */                                         \
-        /* the loads of two levels ahead */                                                                             \
-        Q4 = rl_u32(R2.w, 0);                                                                                           \
-        S2 = buf_ld16(stat_rs, R2.y * 16u);                                                                             \
-        R4 = buf_ld16(rec_rs, Q4 * (TM_REC_DW * 4u) + grp16);                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-        const int visit = (int)(SC.x & vmask);                                                                          \
-        const uint64_t lowmask = __builtin_amdgcn_ballot_w64(visit < low) & onm;                                        \
-        uint64_t selmask;                                                                                               \
-        if (__builtin_expect(lowmask != 0ull, 0)) {                                                                     \
-            uint64_t mm = lowmask & 0x0101010101010101ull;                                                              \
-            const int m = __popcll(mm);                                                                                 \
-            const uint32_t r = wave_rand_lds(L.misc, rng_pos, lane);                                                    \
-            const int kth = (int)(r % (uint32_t)m);                                                                     \
-            for (int t = 0; t < kth; ++t) mm &= mm - 1;                                                                 \
-            selmask = mm;                                                                                               \
-        } else {                                                                                                        \
-            const int n = (int)group_sum_u32((uint32_t)visit);                                                          \
-            int cbits;                                                                                                  \
-            if (__builtin_expect(n >= nq_size, 0)) {                                                                    \
-                cbits = __builtin_amdgcn_readfirstlane(__float_as_int(norm_quantile_dev((double)n)));                   \
-                nq_fallback += 1;                                                                                       \
-            } else {                                                                                                    \
-                TM_NQ_LOOKUP(cbits, n)                                                                                  \
-            }                                                                                                           \
-            const float own = rl_f32(__uint_as_float(RC.z), 56);     /* piece 7, word 2 (word 3 of piece 0 is taken) */ \
-            const float t1 = __uint_as_float(SC.y) + __uint_as_float(RC.z);                                             \
-            float val = t1 - own;                                                                                       \
-            TM_NQ_WAIT(cbits, val)                                                                                      \
-            const float prod = __int_as_float(cbits) * __uint_as_float(SC.w);                                           \
-            const float q = (val + prod) + 0.0f;                                                                        \
-            const uint32_t qb = __float_as_uint(q);                                                                     \
-            int key = (int)(qb ^ (((uint32_t)((int)qb >> 31)) >> 1));                                                   \
-            key = (q != q) ? nan_key : key;                                                                             \
-            key = (RC.x != 0u && lane < 56) ? key : (int)0x80000000;                                                    \
-            const int kmax = group_max_i32(key);                                                                        \
-            selmask = __builtin_amdgcn_ballot_w64(key == kmax);                                                         \
-        }                                                                                                               \
-        const uint32_t c = rl_u32(RC.x, __builtin_ctzll(selmask) & 56);                                                 \
-        const uint32_t my_p = rl_u32(RC.x, 56), my_pp = rl_u32(RC.w, 0);                                                \
-        /* keep the predictions true: this node's child, the previous node's grandchild */                             \
-        if (__builtin_expect(my_p != c, 0)) {                                                                           \
-            if (lane == 56) P.rec()[(size_t)QC * TM_REC_DW + TM_REC_PCHILD] = c;                                        \
-        }                                                                                                               \
-        if (__builtin_expect(prev_node != 0u && prev_pp != c, 0)) {                                                     \
-            if (lane == 0) P.rec()[(size_t)prev_node * TM_REC_DW + 3] = c;                                              \
-        }                                                                                                               \
-        if (__builtin_expect(c != Q1, 0)) {                                                                             \
-            /* not the child whose record is in R1: restart at the selected child */                                    \
-            TM_WALK_START(c, R1, Q1, S1, R2, Q2, R3, Q3, S2, R4, Q4)                                                    \
-            n_miss += 1;                                                                                                \
-        }                                                                                                               \
-        prev_node = QC;                                                                                                 \
-        prev_pp = my_pp;                                                                                                \
-    }
-    for (;;) {
-        TM_WALK_LEVEL(r0, q0, s0, r1, q1, s1, r2, q2, s2, r3, q3, r4, q4)
-        TM_WALK_LEVEL(r1, q1, s1, r2, q2, s2, r3, q3, s0, r4, q4, r5, q5)
-        TM_WALK_LEVEL(r2, q2, s2, r3, q3, s0, r4, q4, s1, r5, q5, r0, q0)
-        TM_WALK_LEVEL(r3, q3, s0, r4, q4, s1, r5, q5, s2, r0, q0, r1, q1)
-        TM_WALK_LEVEL(r4, q4, s1, r5, q5, s2, r0, q0, s0, r1, q1, r2, q2)
-        TM_WALK_LEVEL(r5, q5, s2, r0, q0, s0, r1, q1, s1, r2, q2, r3, q3)
-    }
-#undef TM_WALK_START
-#else
     // three record register sets and two statistics sets rotate through the roles (current node, predicted child,
     // predicted grandchild) / (this level, next level): the loop body is instantiated six times instead of moving
     // eleven registers per level.  p0..p2 = predicted child (piece 7, word 0) of the node held in r0..r2.
@@ -1046,7 +935,6 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         TM_WALK_LEVEL(r1, p1, s0, r2, p2, s1, r0)
         TM_WALK_LEVEL(r2, p2, s1, r0, p0, s0, r1)
     }
-#endif
 #undef TM_WALK_LEVEL
 #undef TM_WALK_PROF
 #undef TM_NQ_LOOKUP
