@@ -507,7 +507,11 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
         wave_sync();
         if (leader) {
             // (child, observation, child score, own score): the walk's lane group for this slot needs nothing else
+#ifdef TM_WALK2
+            reinterpret_cast<uint4*>(r)[slot] = make_uint4(best_c, my_o, __float_as_uint(best_s), slot == 0 ? 0u : self_sc);
+#else
             reinterpret_cast<uint4*>(r)[slot] = make_uint4(best_c, my_o, __float_as_uint(best_s), self_sc);
+#endif
             L.misc[16 + slot] = best_c;                 // slot-ordered copies for the evaluation requests
             L.misc[24 + slot] = my_o;
             L.misc[32 + slot] = __float_as_uint(best_s);
@@ -847,6 +851,158 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
 #define TM_NQ_LOOKUP(CB, N) asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(CB) : "s"(nq_base), "s"((N) << 2));
 #define TM_NQ_WAIT(CB, V)
 #endif
+#ifdef TM_WALK2
+    // EXPERIMENTAL (not the default build): two levels per memory round trip.  A record also holds the
+    // predicted GRANDchild (piece 0, word 3), so the record of level j+4 is requested as soon as the record of level j+2
+    // is here, and the statistics of level j+2's children with it: every load is issued two levels before its use and a
+    // level waits only for loads that are two levels old.  Six record quads r0..r5 (node ids q0..q5) and three statistics
+    // quads s0..s2 rotate through six instances of the level body: level j reads r[j] / s[j%3], assumes r[j+1] is its
+    // child, uses r[j+2] to issue s[(j+2)%3] and r[j+4].  A selection that differs from the assumed child rewrites the
+    // predictions it contradicts, leaves the steady loop and restarts the pipeline at the selected child.
+    // Loads and waits are inline assembly on PINNED register quads: the compiler's own s_waitcnt insertion waited for the
+    // newest load at every level (copies at register merges), and with unpinned assembly loads the allocator copied quads
+    // that were still in flight.  Loads return in order, so "at most N younger loads outstanding" = s_waitcnt vmcnt(N);
+    // stores issued in between only make a wait stricter.  A loaded quad is read only through the wait that names it.
+    typedef uint32_t tm_u32x4 __attribute__((ext_vector_type(4)));
+    auto mk_rs = [](const void* p_, size_t bytes) {
+        const uint64_t a_ = (uint64_t)p_;
+        tm_u32x4 v_;
+        v_.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a_);
+        v_.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a_ >> 32)) & 0xFFFFu;
+        v_.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bytes);
+        v_.w = 0x00020000u;
+        return v_;
+    };
+    const tm_u32x4 rec_q = mk_rs(P.rec(), P.n() * (TM_REC_DW * 4u)), stat_q = mk_rs(P.stat(), P.n() * 16u);
+#define TM_C_R0 "{v[88:91]}"
+#define TM_C_R1 "{v[92:95]}"
+#define TM_C_R2 "{v[96:99]}"
+#define TM_C_R3 "{v[100:103]}"
+#define TM_C_R4 "{v[104:107]}"
+#define TM_C_R5 "{v[108:111]}"
+#define TM_C_S0 "{v[112:115]}"
+#define TM_C_S1 "{v[116:119]}"
+#define TM_C_S2 "{v[120:123]}"
+#define TM_ALD(DST, CSTR, RS, OFF) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=" CSTR(DST) : "v"((uint32_t)(OFF)), "s"(RS));
+#define TM_AWAIT1(N, A, AC) asm volatile("s_waitcnt vmcnt(" #N ")" : "+" AC(A));
+#define TM_AWAIT2(N, A, AC, B, BC) asm volatile("s_waitcnt vmcnt(" #N ")" : "+" AC(A), "+" BC(B));
+    tm_u32x4 r0 = {0, 0, 0, 0}, r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, s0 = r0, s1 = r0, s2 = r0;
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
+    // every load in flight targets one of the nine quads: they stay reserved until this wait has been passed
+#define TM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" :: TM_C_R0(r0), TM_C_R1(r1), TM_C_R2(r2), TM_C_R3(r3), TM_C_R4(r4), \
+                                TM_C_R5(r5), TM_C_S0(s0), TM_C_S1(s1), TM_C_S2(s2) : "memory");
+    uint32_t prev_node = 0, prev_pp = 0;
+    int cur_node = idx;
+    // (re)start at node C: A = its record, B / C_ = predicted child / grandchild, D = B's predicted grandchild
+#define TM_WALK_START(C, RA, CA, QA, SA, CSA, RB, CB, QB, RC_, CC, QC, SB, CSB, RD, CD, QD)                             \
+    {                                                                                                                   \
+        QA = (C);                                                                                                       \
+        TM_DRAIN()                                          /* whatever the abandoned path still had in flight */       \
+        TM_ALD(RA, CA, rec_q, QA * (TM_REC_DW * 4u) + grp16)                                                            \
+        TM_AWAIT1(0, RA, CA)                                                                                            \
+        QB = rl_u32(RA.x, 56);                                                                                          \
+        QC = rl_u32(RA.w, 0);                                                                                           \
+        TM_ALD(SA, CSA, stat_q, RA.y * 16u)                                                                             \
+        TM_ALD(RB, CB, rec_q, QB * (TM_REC_DW * 4u) + grp16)                                                            \
+        TM_ALD(RC_, CC, rec_q, QC * (TM_REC_DW * 4u) + grp16)                                                           \
+        TM_AWAIT1(1, RB, CB)                                                                                            \
+        QD = rl_u32(RB.w, 0);                                                                                           \
+        TM_ALD(SB, CSB, stat_q, RB.y * 16u)                                                                             \
+        TM_ALD(RD, CD, rec_q, QD * (TM_REC_DW * 4u) + grp16)                                                            \
+    }
+#define TM_WALK_LEVEL(RC, QC, SC, CSC, Q1, R2, CR2, S2, CS2, R4, CR4, Q4)                                               \
+    {                                                                                                                   \
+        if (__builtin_expect((len & (TRACE_LDS - 1)) == 0, 0)) {                                                        \
+            if (len != 0) {      /* the LDS trace buffer is full */                                                     \
+                if (len >= max_trace) { overflow = true; walk_done = true; break; }                                     \
+                wave_sync(); flush_trace(len); wave_sync();                                                             \
+                if (lane == 56) tp = &L.tbuf[0];                                                                        \
+            }                                                                                                           \
+        }                                                                                                               \
+        *tp = make_uint4(RC.x, RC.y, RC.z, RC.w);   /* lane 56: piece 7 */                                              \
+        tp += tinc;                                                                                                     \
+        len += 1;                                                                                                       \
+        cur_node = (int)QC;                                                                                             \
+        const uint64_t onm = __builtin_amdgcn_ballot_w64(RC.x != 0u) & lanes_lt56;                                      \
+        if (onm == 0ull) { walk_done = true; break; } /* no children: a leaf */                                         \
+        /* the loads of two levels ahead */                                                                             \
+        TM_AWAIT2(2, SC, CSC, R2, CR2)   /* issued two levels ago; the previous level's pair may still be in flight */  \
+        Q4 = rl_u32(R2.w, 0);                                                                                           \
+        TM_ALD(S2, CS2, stat_q, R2.y * 16u)                                                                             \
+        TM_ALD(R4, CR4, rec_q, Q4 * (TM_REC_DW * 4u) + grp16)                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        const int visit = (int)(SC.x & vmask);                                                                          \
+        const uint64_t lowmask = __builtin_amdgcn_ballot_w64(visit < low) & onm;                                        \
+        uint64_t selmask;                                                                                               \
+        if (__builtin_expect(lowmask != 0ull, 0)) {                                                                     \
+            uint64_t mm = lowmask & 0x0101010101010101ull;                                                              \
+            const int m = __popcll(mm);                                                                                 \
+            const uint32_t r = wave_rand_lds(L.misc, rng_pos, lane);                                                    \
+            const int kth = (int)(r % (uint32_t)m);                                                                     \
+            for (int t = 0; t < kth; ++t) mm &= mm - 1;                                                                 \
+            selmask = mm;                                                                                               \
+        } else {                                                                                                        \
+            const int n = (int)group_sum_u32((uint32_t)visit);                                                          \
+            int cbits;                                                                                                  \
+            if (__builtin_expect(n >= nq_size, 0)) {                                                                    \
+                cbits = __builtin_amdgcn_readfirstlane(__float_as_int(norm_quantile_dev((double)n)));                   \
+                nq_fallback += 1;                                                                                       \
+            } else {                                                                                                    \
+                TM_NQ_LOOKUP(cbits, n)                                                                                  \
+            }                                                                                                           \
+            const float own = rl_f32(__uint_as_float(RC.z), 56);     /* piece 7, word 2 (word 3 of piece 0 is taken) */ \
+            const float t1 = __uint_as_float(SC.y) + __uint_as_float(RC.z);                                             \
+            float val = t1 - own;                                                                                       \
+            TM_NQ_WAIT(cbits, val)                                                                                      \
+            const float prod = __int_as_float(cbits) * __uint_as_float(SC.w);                                           \
+            const float q = (val + prod) + 0.0f;                                                                        \
+            const uint32_t qb = __float_as_uint(q);                                                                     \
+            int key = (int)(qb ^ (((uint32_t)((int)qb >> 31)) >> 1));                                                   \
+            key = (q != q) ? nan_key : key;                                                                             \
+            key = (RC.x != 0u && lane < 56) ? key : (int)0x80000000;                                                    \
+            const int kmax = group_max_i32(key);                                                                        \
+            selmask = __builtin_amdgcn_ballot_w64(key == kmax);                                                         \
+        }                                                                                                               \
+        const uint32_t c = rl_u32(RC.x, __builtin_ctzll(selmask) & 56);                                                 \
+        const uint32_t my_p = rl_u32(RC.x, 56), my_pp = rl_u32(RC.w, 0);                                                \
+        /* keep the predictions true: this node's child, the previous node's grandchild */                             \
+        if (__builtin_expect(my_p != c, 0)) {                                                                           \
+            if (lane == 56) P.rec()[(size_t)QC * TM_REC_DW + TM_REC_PCHILD] = c;                                        \
+        }                                                                                                               \
+        if (__builtin_expect(prev_node != 0u && prev_pp != c, 0)) {                                                     \
+            if (lane == 0) P.rec()[(size_t)prev_node * TM_REC_DW + 3] = c;                                              \
+        }                                                                                                               \
+        prev_node = QC;                                                                                                 \
+        prev_pp = my_pp;                                                                                                \
+        if (__builtin_expect(c != Q1, 0)) {                                                                             \
+            /* not the child whose record was assumed: leave the steady loop, restart at the selected child */          \
+            restart_node = c;                                                                                           \
+            n_miss += 1;                                                                                                \
+            break;                                                                                                      \
+        }                                                                                                               \
+    }
+    uint32_t restart_node = (uint32_t)idx;
+    bool walk_done = false;
+    for (;;) {
+        // (re)start: always into the first rotation position
+        TM_WALK_START(restart_node, r0, TM_C_R0, q0, s0, TM_C_S0, r1, TM_C_R1, q1, r2, TM_C_R2, q2, s1, TM_C_S1, r3, TM_C_R3, q3)
+        for (;;) {
+            TM_WALK_LEVEL(r0, q0, s0, TM_C_S0, q1, r2, TM_C_R2, s2, TM_C_S2, r4, TM_C_R4, q4)
+            TM_WALK_LEVEL(r1, q1, s1, TM_C_S1, q2, r3, TM_C_R3, s0, TM_C_S0, r5, TM_C_R5, q5)
+            TM_WALK_LEVEL(r2, q2, s2, TM_C_S2, q3, r4, TM_C_R4, s1, TM_C_S1, r0, TM_C_R0, q0)
+            TM_WALK_LEVEL(r3, q3, s0, TM_C_S0, q4, r5, TM_C_R5, s2, TM_C_S2, r1, TM_C_R1, q1)
+            TM_WALK_LEVEL(r4, q4, s1, TM_C_S1, q5, r0, TM_C_R0, s0, TM_C_S0, r2, TM_C_R2, q2)
+            TM_WALK_LEVEL(r5, q5, s2, TM_C_S2, q0, r1, TM_C_R1, s1, TM_C_S1, r3, TM_C_R3, q3)
+        }
+        if (walk_done) break;
+    }
+    TM_DRAIN()      // the loads of the last two levels are still in flight: nothing may reuse their registers before this
+#undef TM_DRAIN
+#undef TM_WALK_START
+#undef TM_ALD
+#undef TM_AWAIT1
+#undef TM_AWAIT2
+#else
     // three record register sets and two statistics sets rotate through the roles (current node, predicted child,
     // predicted grandchild) / (this level, next level): the loop body is instantiated six times instead of moving
     // eleven registers per level.  p0..p2 = predicted child (piece 7, word 0) of the node held in r0..r2.
@@ -935,6 +1091,7 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         TM_WALK_LEVEL(r1, p1, s0, r2, p2, s1, r0)
         TM_WALK_LEVEL(r2, p2, s1, r0, p0, s0, r1)
     }
+#endif
 #undef TM_WALK_LEVEL
 #undef TM_WALK_PROF
 #undef TM_NQ_LOOKUP
