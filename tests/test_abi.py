@@ -71,3 +71,54 @@ def test_play_cli_keeps_the_reference_flags():
     d = vars(p.parse_args([]))
     for k, v in ref.items():
         assert d[k] == v and type(d[k]) is type(v), k
+
+
+def _is_message(call):
+    """print / raise / warn texts may name the oracle."""
+    import ast
+    f = call.func
+    name = f.id if isinstance(f, ast.Name) else getattr(f, "attr", "")
+    return name in ("print", "warn", "RuntimeError", "ValueError", "NotImplementedError", "write", "format", "join")
+
+
+def test_the_product_never_touches_the_oracle():
+    """The oracle is the checker: nothing under tetris_mcts_amd/ (nor the root module shims, play.py, the C sources) may
+    import, load or execute it; bench.py may only inside its cpu_baseline leg (functions named _cpu_* / cpu_baseline),
+    __graft_entry__ only inside smoke()."""
+    import ast
+    product = []
+    for base, _dirs, files in os.walk(os.path.join(ROOT, "tetris_mcts_amd")):
+        product += [os.path.join(base, f) for f in files if f.endswith((".py", ".hip", ".h"))]
+    product += [os.path.join(ROOT, f) for f in ("play.py", "pyTetris.py")]
+    product += [os.path.join(ROOT, "agents", f) for f in os.listdir(os.path.join(ROOT, "agents")) if f.endswith(".py")]
+    for path in product:
+        text = open(path).read()
+        if path.endswith(".py"):
+            tree = ast.parse(text)
+            for n in ast.walk(tree):
+                if isinstance(n, ast.ImportFrom):
+                    assert (n.module or "").split(".")[0] != "oracle", path
+                if isinstance(n, ast.Import):
+                    assert all(a.name.split(".")[0] != "oracle" for a in n.names), path
+                if isinstance(n, ast.Call) and not _is_message(n):
+                    # no path or module name with "oracle" in it handed to any call (CDLL, import_module, open ...)
+                    for arg in list(n.args) + [k.value for k in n.keywords]:
+                        names = [c.value for c in ast.walk(arg) if isinstance(c, ast.Constant) and isinstance(c.value, str)]
+                        assert not any("oracle" in v for v in names), (path, n.lineno)
+        else:
+            assert not [ln for ln in text.splitlines() if "#include" in ln and "oracle" in ln], path
+
+    def oracle_users(path):
+        tree = ast.parse(open(path).read())
+        users = set()
+        for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]:
+            for n in ast.walk(fn):
+                if isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle":
+                    users.add(fn.name)
+                if isinstance(n, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in n.names):
+                    users.add(fn.name)
+        top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+        assert not any((getattr(n, "module", None) or "").startswith("oracle") for n in top), path
+        return users
+    assert oracle_users(os.path.join(ROOT, "bench.py")) <= {"_cpu_worker", "cpu_baseline"}
+    assert oracle_users(os.path.join(ROOT, "__graft_entry__.py")) <= {"smoke"}
