@@ -62,12 +62,14 @@ enum {
     TM_GS_SIM_TARGET = 40, TM_GS_SIM_STARTED,
     TM_GS_CYC_WALK_MEM,  /* profiling builds (-DTM_PROF_WALK): cycles of the last walk spent waiting for its loads */
     TM_GS_N_WALK_MISS,   /* tree levels at which the walk descended into another child than the predicted one (all simulations) */
-    TM_GS_POOL_FULL      /* the reachable tree fills the pool (TM_ERR_POOL): no collection is attempted until the root moves */
+    TM_GS_POOL_FULL,     /* the reachable tree fills the pool (TM_ERR_POOL): no collection is attempted until the root moves */
+    TM_GS_REQ_SEQ        /* -DTM_OVERLAP builds: sequence number of the launch whose requests (eval_obs) are complete */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
 #define TM_ERR_TRACE 2     /* trace longer than max_trace */
 #define TM_ERR_TABLE 4     /* transposition table full */
+#define TM_ERR_EVAL_TIMEOUT 8 /* -DTM_OVERLAP builds: the evaluator gave up waiting for this game's requests */
 
 /* agent numerics (which reference twin is reproduced bit for bit) */
 #define TM_KIND_VALUESIM 0     /* agents/ValueSim.py:76-94      : evaluate the leaf, fp64 carry             */

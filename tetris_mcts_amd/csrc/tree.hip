@@ -263,6 +263,21 @@ __device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, u
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane);
 __device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, int lane, long long budget);
 
+// -DTM_OVERLAP builds (EXPERIMENTAL): the evaluator's convolution kernel runs beside this kernel and
+// picks a game's requests up as soon as the game's wave has published them.  What the evaluator reads - the request words
+// and the packed key of an observation created in this launch - is stored with relaxed agent-scope stores (sc1: written
+// through), the wave waits for its stores and then publishes the launch's sequence number in its control block; the
+// consumer reads with sc1 loads.  No fences (MI355X_MICROARCH.md, valid hand-off forms).
+#ifdef TM_OVERLAP
+#define TM_REQ_ST(LVALUE, V) __hip_atomic_store(&(LVALUE), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define TM_PUBLISH() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+                       if (lane == 0) __hip_atomic_store(&gs[TM_GS_REQ_SEQ], (int)((unsigned)flags >> 8), __ATOMIC_RELAXED, \
+                                                         __HIP_MEMORY_SCOPE_AGENT); }
+#else
+#define TM_REQ_ST(LVALUE, V) (LVALUE) = (V)
+#define TM_PUBLISH()
+#endif
+
 #ifdef TM_PROF_EXPAND   /* instrumented build: cycles since the start of the expansion at probe i -> control word 48 + i */
 #define TM_XP_START(L) { const long long t_ = __builtin_readcyclecounter(); (L).misc[62] = (uint32_t)t_; }
 #define TM_XP(L, P, i) { if (lane == 0) (P).gs()[48 + (i)] = (int)((uint32_t)__builtin_readcyclecounter() - (L).misc[62]); }
@@ -368,9 +383,15 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     if (n == 7) TM_XP(L, P, 7)
     if (onew) {
         uint4* dst = reinterpret_cast<uint4*>(P.okey() + (size_t)o * OBS_DW);
+#ifdef TM_OVERLAP
+        for (int t = 0; t < 6; ++t)
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(dst) + t, (uint64_t)ok[2 * t] | ((uint64_t)ok[2 * t + 1] << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         dst[0] = make_uint4(ok[0], ok[1], ok[2], ok[3]);
         dst[1] = make_uint4(ok[4], ok[5], ok[6], ok[7]);
         dst[2] = make_uint4(ok[8], ok[9], ok[10], ok[11]);
+#endif
         // visit, value, variance = 0 and obs_arrays['end'] (agents/agent.py:123): slots are initialised when they are
         // handed out, so the GC does not have to clear the key / record streams of everything it frees
         *reinterpret_cast<uint4*>(P.stat() + (size_t)o * 4) = make_uint4((ok[11] & 1u) << 31, 0u, 0u, 0u);
@@ -741,16 +762,16 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
     if (!leaf_end) {
         uint32_t lh;
         if (!wave_expand(S, P, L, g, lane, leaf, self_sc, lh, gsv)) {
-            if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
+            if (lane < S.eval_slots) TM_REQ_ST(P.eval_obs()[lane], 0);
             if (lane == 0) P.gs()[TM_GS_PENDING] = 2;
             return;
         }
         if (VANILLA) {
             k_eval = 0;
-            if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
+            if (lane < S.eval_slots) TM_REQ_ST(P.eval_obs()[lane], 0);
         } else if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT) {
             k_eval = 1;
-            if (lane == 0) P.eval_obs()[0] = (int)self_o;
+            if (lane == 0) TM_REQ_ST(P.eval_obs()[0], (int)self_o);
         } else {
             // unique children of the freshly expanded leaf (ValueSimLP.py:55 / agent.cpp:424)
             const int nu = (int)(lh & 7u);
@@ -760,12 +781,12 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
                 P.leaf()[lane] = on ? (int)L.misc[16 + lane] : 0;
                 P.leaf()[7 + lane] = on ? (int)L.misc[24 + lane] : 0;
                 P.leaf()[14 + lane] = on ? (int)L.misc[32 + lane] : 0;
-                P.eval_obs()[lane] = on ? (int)L.misc[24 + lane] : 0;
+                TM_REQ_ST(P.eval_obs()[lane], on ? (int)L.misc[24 + lane] : 0);
             }
         }
         if (lane == 0) P.gs()[TM_GS_N_EXPAND] = GSV(gsv, TM_GS_N_EXPAND) + 1;
     } else {
-        if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
+        if (lane < S.eval_slots) TM_REQ_ST(P.eval_obs()[lane], 0);
     }
     if (lane == 0) {
         int32_t* gs = P.gs();
@@ -1442,7 +1463,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         // this game is collecting garbage: one slice per launch (S.gc_slice_cycles; 0 = to completion), no simulation
         // (catch-up launches pass TM_SIM_GC_FULL: only laggards are left, nobody is held up by a collection run to its end)
         const bool sliced = S.gc_slice_cycles > 0 && !(flags & TM_SIM_GC_FULL);
-        if (!gc_run(S, P, g, lane, sliced ? (long long)S.gc_slice_cycles : -1)) return;
+        if (!gc_run(S, P, g, lane, sliced ? (long long)S.gc_slice_cycles : -1)) { TM_PUBLISH() return; }
         gsv = gs[lane];
     }
     const int pend = GSV(gsv, TM_GS_PENDING);
@@ -1452,6 +1473,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         const uint32_t self_o = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_OBS];
         const uint32_t self_sc = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_SCORE];
         wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc, gsv);
+        TM_PUBLISH()
         return;
     }
 #ifndef TM_NO_SETPRIO
@@ -1475,7 +1497,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     // the per-move quota (tm_move_begin): games that lost launches to a collection catch up in extra launches
     if ((flags & TM_SIM_FRONT) && GSV(gsv, TM_GS_SIM_STARTED) < GSV(gsv, TM_GS_SIM_TARGET))
         wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane, gsv);
-    else if (lane < S.eval_slots) P.eval_obs()[lane] = 0;      // nothing started: no request (the evaluator skips empty slots)
+    else if (lane < S.eval_slots) TM_REQ_ST(P.eval_obs()[lane], 0);   // nothing started: no request (the evaluator skips empty slots)
+    TM_PUBLISH()
 }
 
 // per-move simulation quota (TreeAgent.play: self.mcts(self.root, self.sims), agents/agent.py:147-150)

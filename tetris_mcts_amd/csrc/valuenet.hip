@@ -210,178 +210,12 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, const in
 #else
 #define TM_CONV_WAVES 1
 #endif
-__global__ __launch_bounds__(256, TM_CONV_WAVES) void k_vn_conv(const float* __restrict__ P, const float* __restrict__ prep,
-                                                    const int8_t* __restrict__ states, const uint32_t* __restrict__ obs_key,
-                                                    const int32_t* __restrict__ eval_obs, int eval_slots, int max_nodes,
-                                                    int n, float* __restrict__ a3out, int a3stride) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-    float* a1 = smem + w * WAVE_LDS;
-#if TM_CONV_WG_PER_CU == 2
-    float* a2 = a1;
-    float* x0 = a1 + 32 * A1CS;
-#else
-    float* a2 = a1 + 32 * A1CS;
-    float* x0 = a2 + 32 * A2CS;
+#include "valuenet_conv.inc"
+#ifdef TM_OVERLAP
+#define TM_CONV_POLLED
+#include "valuenet_conv.inc"
+#undef TM_CONV_POLLED
 #endif
-    // ---- per-lane constants ----
-    int koff2[9], koff3[9];   // offsets of k = 2j+half inside a two-channel block
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        int k = 2 * j + half, ci = k / 9, r = k - 9 * ci, ky = r / 3, kx = r - 3 * ky;
-        koff2[j] = ci * A1CS + ky * 8 + kx;
-        koff3[j] = ci * A2CS + ky * 6 + kx;
-    }
-    int boff2[3][9], boff3[2][9];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        int p = 32 * t + l31, y = p / 6, x = p - 6 * y;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) boff2[t][j] = y * 8 + x + koff2[j];
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        int p = min(32 * t + l31, 55), y = p / 4, x = p - 4 * y;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) boff3[t][j] = y * 6 + x + koff3[j];
-    }
-    float bias2[16], bias3[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        bias2[r] = P[OFF_C2B + i];
-        bias3[r] = P[OFF_C3B + i];
-    }
-    float w1[5];      // conv1 weights: A operand of step st = W1[co = l31][k = 2 st + half], k = 9 is the zero pad
-    int koff1[5];
-#pragma unroll
-    for (int st = 0; st < 5; ++st) {
-        const int k = 2 * st + half;
-        w1[st] = (k < 9) ? P[OFF_C1W + l31 * 9 + k] : 0.0f;
-        koff1[st] = (k < 9) ? (k / 3) * 10 + (k % 3) : 0;
-    }
-    const float4* W2 = reinterpret_cast<const float4*>(prep + PREP_W2) + lane;
-    const float4* W3 = reinterpret_cast<const float4*>(prep + PREP_W3) + lane;
-
-    // Evaluation requests: the two dependent global reads per state (request -> packed observation) are issued one
-    // state ahead, so they are in flight under the previous state's convolutions instead of in front of this one's.
-    const int stride = gridDim.x * 4;
-    int s = blockIdx.x * 4 + w;
-    int o_next = (!states && s < n) ? eval_obs[s] : 0;
-    uint32_t kw_next = 0;
-    if (!states && s < n && lane < 12) kw_next = obs_key[((size_t)(s / eval_slots) * max_nodes + o_next) * 12 + lane];
-    for (; s < n; s += stride) {
-        // weight streams re-read per state (an opaque zero offset defeats hoisting them into ~290 registers) so the
-        // kernel fits in 256 registers and two waves share a SIMD
-        int zoff = 0;
-        asm volatile("" : "+s"(zoff));
-        const float4* W2s = W2 + zoff;
-        const float4* W3s = W3 + zoff;
-        const int o = o_next;
-        const uint32_t kw = kw_next;
-        const int sn = s + stride;
-        if (!states) {
-            o_next = (sn < n) ? eval_obs[sn] : 0;
-            // unused evaluation slots (request 0) are skipped: their outputs are never read
-            if (o == 0) {
-                kw_next = (sn < n && lane < 12) ? obs_key[((size_t)(sn / eval_slots) * max_nodes + o_next) * 12 + lane] : 0u;
-                continue;
-            }
-        }
-        // ---- input ----
-        if (states) {
-            for (int i = lane; i < 200; i += 64) x0[i] = (float)states[(size_t)s * 200 + i];
-        } else {
-            const uint32_t cells = __shfl((int)kw, 10, 64), endw = __shfl((int)kw, 11, 64);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {   // uniform trip count: the shuffles below need every lane active
-                const int i = lane + 64 * it, ic = min(i, 199);
-                int r = ic / 10, c = ic - 10 * r;
-                uint32_t w2 = (uint32_t)__shfl((int)kw, r >> 1, 64);
-                float v = (float)((w2 >> (16 * (r & 1) + c)) & 1u);
-                bool pc = ((cells & 0xFF) == (uint32_t)ic) | (((cells >> 8) & 0xFF) == (uint32_t)ic) |
-                          (((cells >> 16) & 0xFF) == (uint32_t)ic) | ((cells >> 24) == (uint32_t)ic);
-                if (!(endw & 0xFFu) && pc) v = -1.0f;
-                if (i < 200) x0[i] = v;
-            }
-            // the next state's observation: its request index has had the whole input stage to arrive
-            kw_next = (sn < n && lane < 12) ? obs_key[((size_t)(sn / eval_slots) * max_nodes + o_next) * 12 + lane] : 0u;
-        }
-        lds_fence();
-        // ---- conv1 (K = 9) on the matrix cores as well: 144 positions = 5 tiles (the last one half padding), 5 steps of
-        // two taps; the tenth tap has weight 0, and fma(0, b, acc) returns acc unchanged for the finite b read there ----
-#if !(TM_CONV_SKIP & 1)
-        {
-#pragma unroll 1
-            for (int t = 0; t < 5; ++t) {
-                const int p = 32 * t + l31, pc = min(p, 143), base = (pc >> 3) * 10 + (pc & 7);
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = P[OFF_C1B + (r & 3) + 8 * (r >> 2) + 4 * half];
-#pragma unroll
-                for (int st = 0; st < 5; ++st)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], x0[base + koff1[st]], acc, 0, 0, 0);
-                if (p < 144) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        a1[i * A1CS + p] = acc[r] > 0.0f ? acc[r] : 0.0f;
-                    }
-                }
-            }
-        }
-#endif
-        lds_fence();
-        // ---- conv2: 96 positions = 3 tiles ----
-        {
-            f32x16 acc[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = bias2[r];
-#if !(TM_CONV_SKIP & 2)
-            conv_mfma<3, A1CS>(a1, boff2, W2s, acc);
-#endif
-#if TM_CONV_WG_PER_CU == 2
-            lds_fence();   // a2 overlays a1: every read of a1 is complete before the first write
-#endif
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = acc[t][r];
-                    a2[i * A2CS + 32 * t + l31] = v > 0.0f ? v : 0.0f;
-                }
-        }
-        lds_fence();
-        // ---- conv3: 56 positions = 2 tiles (the last 8 lanes of tile 1 are padding) ----
-        {
-            f32x16 acc[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = bias3[r];
-#if !(TM_CONV_SKIP & 4)
-            conv_mfma<2, A2CS>(a2, boff3, W3s, acc);
-#endif
-            float* dst = a3out + (size_t)s * a3stride;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                int p = 32 * t + l31;
-                if (p < 56) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float v = acc[t][r];
-                        dst[i * 56 + p] = v > 0.0f ? v : 0.0f;
-                    }
-                }
-            }
-        }
-        lds_fence();
-    }
-}
 
 // fc1 (1792 -> 256) + ReLU on v_mfma_f32_16x16x4_f32 (D[16x16] += A[16x4] B[4x16]; lane l: A[i=l&15][k=l>>4],
 // B[k=l>>4][j=l&15], D[i=(l>>4)*4+r][j=l&15]; per output a k-ordered fma chain, 4 terms per instruction).
@@ -525,6 +359,37 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, v, var, n, eval_obs);
     return (int)hipGetLastError();
 }
+
+#ifdef TM_OVERLAP
+// EXPERIMENTAL (-DTM_OVERLAP builds only, called by search.hip): the request form of the forward pass launched BESIDE the
+// tree kernel of the same simulation on another stream.  One convolution workgroup per CU (the tree kernel's workgroups
+// share the CU); a wave takes a slot when the slot's game has published `seq` (tree.hip, end of k_sim_step).
+int tm_valuenet_forward_requests_polled(const float* P, const float* prepared, const tm_store* s, float* scratch, int seq,
+                                        void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int n = s->n_games * s->eval_slots;
+    if (n <= 0) return 0;
+    constexpr int SS = TM_VALUENET_SCRATCH_MFMA;
+    static bool attr_set = false;
+    const int lds = 4 * WAVE_LDS * (int)sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_vn_conv_polled),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int blocks = (n + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    const long long spin_cycles = 50000000ll;      // about 20 ms: a collection run to its end takes 3
+    hipLaunchKernelGGL(k_vn_conv_polled, dim3(blocks), dim3(256), lds, stream, P, prepared, (const int8_t*)nullptr, s->obs_key,
+                       s->eval_obs, s->eval_slots, s->max_nodes, n, scratch, SS, s->gs, seq, spin_cycles);
+    hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(512), 0, stream, P, prepared, scratch, SS, n, scratch + A3, SS,
+                       s->eval_obs);
+    hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, s->eval_v, s->eval_var, n,
+                       s->eval_obs);
+    return (int)hipGetLastError();
+}
+#endif
 
 // matrix-core path; prepared: tm_valuenet_prepare output; scratch: n x TM_VALUENET_SCRATCH_MFMA floats
 int tm_valuenet_forward(const float* P, const float* prepared, const int8_t* states, int n, float* v, float* var,
