@@ -51,6 +51,8 @@ enum {
     TM_GS_CYC_TAIL,      /* duration of the last GC in units of 16 cycles; +1: nodes reachable at that GC */
     TM_GS_N_DROPPED = 25, /* replay tuples a GC could not store because the harvest buffer was full (drain it more often) */
     TM_GS_LOW_NODE = 26, TM_GS_LOW_OBS,  /* lowest node / observation index ever allocated (GC skips untouched entries) */
+    TM_GS_FIRST_MISS = 28, /* tree level at which the last walk first left its node's predicted child (= its length if it never did) */
+    TM_GS_PREFIX_SUM,      /* sum of TM_GS_FIRST_MISS over all simulations */
     /* resumable garbage collection (a game that collects does not simulate in that launch) */
     TM_GS_GC_PHASE = 32, /* 0 none, 1 requested, 2 marking, 3 clearing the tables, 4 sweeping, 5 re-inserting */
     TM_GS_GC_CURSOR, TM_GS_GC_TAIL, TM_GS_GC_NFREE, TM_GS_GC_ONFREE,
@@ -60,16 +62,14 @@ enum {
     /* per-move simulation quota: tm_move_begin adds `sims` to the target; a launch starts a simulation for a game only
        while started < target, so games that lost launches to a collection catch up in extra launches (tm_sims_remaining) */
     TM_GS_SIM_TARGET = 40, TM_GS_SIM_STARTED,
-    TM_GS_CYC_WALK_MEM,  /* profiling builds (-DTM_PROF_WALK): cycles of the last walk spent waiting for its loads */
+    TM_GS_RESERVED42,
     TM_GS_N_WALK_MISS,   /* tree levels at which the walk descended into another child than the predicted one (all simulations) */
-    TM_GS_POOL_FULL,     /* the reachable tree fills the pool (TM_ERR_POOL): no collection is attempted until the root moves */
-    TM_GS_REQ_SEQ        /* -DTM_OVERLAP builds: sequence number of the launch whose requests (eval_obs) are complete */
+    TM_GS_POOL_FULL      /* the reachable tree fills the pool (TM_ERR_POOL): no collection is attempted until the root moves */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
 #define TM_ERR_TRACE 2     /* trace longer than max_trace */
 #define TM_ERR_TABLE 4     /* transposition table full */
-#define TM_ERR_EVAL_TIMEOUT 8 /* -DTM_OVERLAP builds: the evaluator gave up waiting for this game's requests */
 
 /* agent numerics (which reference twin is reproduced bit for bit) */
 #define TM_KIND_VALUESIM 0     /* agents/ValueSim.py:76-94      : evaluate the leaf, fp64 carry             */

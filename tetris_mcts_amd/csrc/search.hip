@@ -36,20 +36,9 @@ struct tm_search {
     int ev_used;
     double tree_ms, nn_ms;
     long long n_timed, n_runs, extra_launches, launches;
-#ifdef TM_OVERLAP
-    // EXPERIMENTAL: the value net of simulation i runs on a second stream BESIDE the tree kernel that
-    // posts its requests; its convolution waves take a game's requests when the game's wave has published `seq`
-    std::vector<hipStream_t> nn_streams;
-    std::vector<hipEvent_t> ev_nn;
-    int seq;
-#endif
 };
 
 #define TM_TRY(x) do { int e_ = (int)(x); if (e_ != 0) return e_; } while (0)
-#ifdef TM_OVERLAP
-extern "C" int tm_valuenet_forward_requests_polled(const float* P, const float* prepared, const tm_store* s, float* scratch,
-                                                   int seq, void* stream);
-#endif
 
 extern "C" {
 
@@ -124,19 +113,6 @@ int tm_search_create(tm_search** out, const tm_store* s, int n_sub, int ev_every
         if (e != hipSuccess) return (int)e;
         h->ev_done.push_back(d);
     }
-#ifdef TM_OVERLAP
-    h->seq = 0;
-    for (int k = 0; k < n_sub; ++k) {
-        hipStream_t st = nullptr;
-        e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        if (e != hipSuccess) return (int)e;
-        h->nn_streams.push_back(st);
-        hipEvent_t d;
-        e = hipEventCreateWithFlags(&d, hipEventDisableTiming);
-        if (e != hipSuccess) return (int)e;
-        h->ev_nn.push_back(d);
-    }
-#endif
     e = hipMalloc(&h->rem_dev, sizeof(int32_t) * n_sub);
     if (e != hipSuccess) return (int)e;
     e = hipHostMalloc(&h->rem_host, sizeof(int32_t) * n_sub, hipHostMallocDefault);
@@ -150,10 +126,6 @@ void tm_search_destroy(tm_search* h) {
     for (auto st : h->streams) if (st && h->own_streams) (void)hipStreamDestroy(st);
     for (auto e : h->ev_done) (void)hipEventDestroy(e);
     for (auto e : h->ev) (void)hipEventDestroy(e);
-#ifdef TM_OVERLAP
-    for (auto st : h->nn_streams) (void)hipStreamDestroy(st);
-    for (auto e : h->ev_nn) (void)hipEventDestroy(e);
-#endif
     (void)hipEventDestroy(h->ev_start);
     if (h->rem_dev) (void)hipFree(h->rem_dev);
     if (h->rem_host) (void)hipHostFree(h->rem_host);
@@ -176,9 +148,6 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
     auto step = [&](int k, int extra = 0) -> int {
         if (h->sub[k].n_games == 0) return 0;
         h->launches += 1;
-#ifdef TM_OVERLAP
-        extra |= h->seq << 8;      // the sequence number every game publishes at the end of this launch
-#endif
         return tm_sim_step(&h->sub[k], TM_SIM_BACKUP | TM_SIM_FRONT | extra, st[k]);
     };
     auto nn = [&](int k) -> int {
@@ -187,46 +156,6 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
         return tm_valuenet_forward_requests(vn_params, vn_prepared, &h->sub[k], scr, st[k]);
     };
     h->ev_used = 0;
-#ifdef TM_OVERLAP
-    if (vn_params) {
-        // tree(i) on the sub-batch's stream, value net(i) on its second stream at the same time (it takes requests as
-        // they are published); tree(i+1) waits for value net(i), value net(i+1) follows value net(i) in stream order
-        if (!h->own_streams) TM_TRY(hipEventRecord(h->ev_start, caller));
-        for (int k = 0; k < K; ++k) TM_TRY(hipStreamWaitEvent(h->nn_streams[k], h->ev_start, 0));
-        h->seq = (h->seq + 1) & 0x7FFFFF;
-        for (int k = 0; k < K; ++k) TM_TRY(step(k));
-        for (int i = 0; i < sims; ++i) {
-            const bool timed = h->ev_every > 0 && (i % h->ev_every) == 0;
-            for (int k = 0; k < K; ++k) {
-                if (h->sub[k].n_games == 0) continue;
-                hipEvent_t* e4 = nullptr;
-                if (timed && k == 0) {
-                    while ((int)h->ev.size() < h->ev_used + 3) {
-                        hipEvent_t e;
-                        TM_TRY(hipEventCreate(&e));
-                        h->ev.push_back(e);
-                    }
-                    e4 = &h->ev[h->ev_used];
-                    h->ev_used += 3;
-                    TM_TRY(hipEventRecord(e4[0], h->nn_streams[k]));
-                }
-                float* scr = vn_scratch + (size_t)h->first[k] * h->full.eval_slots * TM_VALUENET_SCRATCH_MFMA;
-                TM_TRY(tm_valuenet_forward_requests_polled(vn_params, vn_prepared, &h->sub[k], scr, h->seq, h->nn_streams[k]));
-                TM_TRY(hipEventRecord(h->ev_nn[k], h->nn_streams[k]));
-                if (e4) TM_TRY(hipEventRecord(e4[1], h->nn_streams[k]));      // value net(i): e4[0] -> e4[1]
-                TM_TRY(hipStreamWaitEvent(st[k], h->ev_nn[k], 0));
-            }
-            h->seq = (h->seq + 1) & 0x7FFFFF;
-            for (int k = 0; k < K; ++k) {
-                TM_TRY(step(k));
-                // (the tree kernel's own duration is not separable here: it runs beside the next value net; e4[2] closes
-                // the triple so that the accounting below stays uniform: e4[1] -> e4[2] = wait + tree launch i+1)
-                if (timed && k == 0 && h->sub[k].n_games) TM_TRY(hipEventRecord(h->ev[h->ev_used - 1], st[k]));
-            }
-        }
-    } else
-#endif
-    {
     for (int k = 0; k < K; ++k) TM_TRY(step(k));
     for (int i = 0; i < sims; ++i) {
         const bool timed = h->ev_every > 0 && (i % h->ev_every) == 0;
@@ -247,7 +176,6 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
             TM_TRY(step(k));
             if (e3) TM_TRY(hipEventRecord(e3[2], st[k]));
         }
-    }
     }
     // catch-up: games that spent launches collecting garbage still owe simulations
     for (;;) {

@@ -263,29 +263,6 @@ __device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, u
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane);
 __device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, int lane, long long budget);
 
-// -DTM_OVERLAP builds (EXPERIMENTAL): the evaluator's convolution kernel runs beside this kernel and
-// picks a game's requests up as soon as the game's wave has published them.  What the evaluator reads - the request words
-// and the packed key of an observation created in this launch - is stored with relaxed agent-scope stores (sc1: written
-// through), the wave waits for its stores and then publishes the launch's sequence number in its control block; the
-// consumer reads with sc1 loads.  No fences (MI355X_MICROARCH.md, valid hand-off forms).
-#ifdef TM_OVERLAP
-#define TM_REQ_ST(LVALUE, V) __hip_atomic_store(&(LVALUE), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define TM_PUBLISH() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
-                       if (lane == 0) __hip_atomic_store(&gs[TM_GS_REQ_SEQ], (int)((unsigned)flags >> 8), __ATOMIC_RELAXED, \
-                                                         __HIP_MEMORY_SCOPE_AGENT); }
-#else
-#define TM_REQ_ST(LVALUE, V) (LVALUE) = (V)
-#define TM_PUBLISH()
-#endif
-
-#ifdef TM_PROF_EXPAND   /* instrumented build: cycles since the start of the expansion at probe i -> control word 48 + i */
-#define TM_XP_START(L) { const long long t_ = __builtin_readcyclecounter(); (L).misc[62] = (uint32_t)t_; }
-#define TM_XP(L, P, i) { if (lane == 0) (P).gs()[48 + (i)] = (int)((uint32_t)__builtin_readcyclecounter() - (L).misc[62]); }
-#else
-#define TM_XP_START(L) {}
-#define TM_XP(L, P, i) {}
-#endif
-
 // `gsv`: the wave's snapshot of the game's control block (word i in lane i), valid when nothing in this launch has changed
 // the free-list words yet (the expansion's first attempt); has_gsv = false: read them from memory (sequential retries,
 // update_root).
@@ -313,9 +290,7 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     int found = 0;
     uint32_t ins = 0;
     bool full = false;
-    if (n == 7) TM_XP(L, P, 2)
     if (uniq) found = table_find(P.ntab(), mask, h, my, P.game(), GAME_DW, ins, full);
-    if (n == 7) TM_XP(L, P, 3)
     bool isnew = uniq && !found && !full;
     uint64_t need = __ballot(isnew);
     int cnt = __popcll(need);
@@ -344,7 +319,6 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         if (lane == 0) { P.gs()[TM_GS_NFREE_NODE] = nfree - cnt; if (lo < low_seen) P.gs()[TM_GS_LOW_NODE] = lo; }
     }
     table_insert_seq(P.ntab(), mask, need, n, lane, h, ins, idx, L.misc);
-    if (n == 7) TM_XP(L, P, 4)
     // 3. observations of the new nodes (agents/agent.py:112-128)
     uint32_t* ok = L.okeys[act ? lane : 0];
     uint64_t ho = 0;
@@ -360,9 +334,7 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     int ofound = 0;
     uint32_t oins = 0;
     bool ofull = false;
-    if (n == 7) TM_XP(L, P, 5)
     if (ouniq) ofound = table_find(P.otab(), mask, ho, ok, P.okey(), OBS_DW, oins, ofull);
-    if (n == 7) TM_XP(L, P, 6)
     bool onew = ouniq && !ofound && !ofull;
     uint64_t oneed = __ballot(onew);
     int ocnt = __popcll(oneed);
@@ -380,18 +352,11 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         if (lane == 0) { P.gs()[TM_GS_NFREE_OBS] = onfree - ocnt; if (lo < olow_seen) P.gs()[TM_GS_LOW_OBS] = lo; }
     }
     table_insert_seq(P.otab(), mask, oneed, n, lane, ho, oins, o, L.misc + 8);
-    if (n == 7) TM_XP(L, P, 7)
     if (onew) {
         uint4* dst = reinterpret_cast<uint4*>(P.okey() + (size_t)o * OBS_DW);
-#ifdef TM_OVERLAP
-        for (int t = 0; t < 6; ++t)
-            __hip_atomic_store(reinterpret_cast<uint64_t*>(dst) + t, (uint64_t)ok[2 * t] | ((uint64_t)ok[2 * t + 1] << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
         dst[0] = make_uint4(ok[0], ok[1], ok[2], ok[3]);
         dst[1] = make_uint4(ok[4], ok[5], ok[6], ok[7]);
         dst[2] = make_uint4(ok[8], ok[9], ok[10], ok[11]);
-#endif
         // visit, value, variance = 0 and obs_arrays['end'] (agents/agent.py:123): slots are initialised when they are
         // handed out, so the GC does not have to clear the key / record streams of everything it frees
         *reinterpret_cast<uint4*>(P.stat() + (size_t)o * 4) = make_uint4((ok[11] & 1u) << 31, 0u, 0u, 0u);
@@ -436,12 +401,10 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
                                    uint32_t self_sc /* float bits of the leaf's own score */, uint32_t& hdr_out, int gsv) {
-    TM_XP_START(L)
     if (lane < GAME_DW) L.slots[7][lane] = P.game()[(size_t)leaf * GAME_DW + lane];
     wave_sync();
     for (int t = lane; t < 7 * GAME_DW; t += 64) L.slots[t >> 4][t & 15] = L.slots[7][t & 15];
     wave_sync();
-    TM_XP(L, P, 0)
     EngCfg cfg{S.app, S.scoring, S.randomizer};
     const int drop = hard_drop_rows(L.slots[7], lane);       // for the successor of action 3: 21 lanes instead of a 20-step loop in one
     if (lane < 7) {
@@ -451,10 +414,8 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
         store_fields(L.slots[lane], p);
     }
     wave_sync();
-    TM_XP(L, P, 1)
     int idx, o;
     wave_new_nodes(S, P, L, g, 7, lane, idx, o, true, gsv);
-    TM_XP(L, P, 8)
     if (idx < 0) {
         // slow path: sequential new_node with a GC at the exhausting pop (rare: once per ~50 moves)
         int out_idx = 0, out_o = 0;
@@ -528,11 +489,7 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
         wave_sync();
         if (leader) {
             // (child, observation, child score, own score): the walk's lane group for this slot needs nothing else
-#ifdef TM_WALK2
-            reinterpret_cast<uint4*>(r)[slot] = make_uint4(best_c, my_o, __float_as_uint(best_s), slot == 0 ? 0u : self_sc);
-#else
             reinterpret_cast<uint4*>(r)[slot] = make_uint4(best_c, my_o, __float_as_uint(best_s), self_sc);
-#endif
             L.misc[16 + slot] = best_c;                 // slot-ordered copies for the evaluation requests
             L.misc[24 + slot] = my_o;
             L.misc[32 + slot] = __float_as_uint(best_s);
@@ -540,7 +497,6 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
         if (lane == 0) { L.misc[56] = hdr; r[TM_REC_HDR] = hdr; }
     }
     wave_sync();
-    TM_XP(L, P, 9)
     hdr_out = L.misc[56];
     return true;
 }
@@ -762,16 +718,16 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
     if (!leaf_end) {
         uint32_t lh;
         if (!wave_expand(S, P, L, g, lane, leaf, self_sc, lh, gsv)) {
-            if (lane < S.eval_slots) TM_REQ_ST(P.eval_obs()[lane], 0);
+            if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
             if (lane == 0) P.gs()[TM_GS_PENDING] = 2;
             return;
         }
         if (VANILLA) {
             k_eval = 0;
-            if (lane < S.eval_slots) TM_REQ_ST(P.eval_obs()[lane], 0);
+            if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
         } else if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT) {
             k_eval = 1;
-            if (lane == 0) TM_REQ_ST(P.eval_obs()[0], (int)self_o);
+            if (lane == 0) P.eval_obs()[0] = (int)self_o;
         } else {
             // unique children of the freshly expanded leaf (ValueSimLP.py:55 / agent.cpp:424)
             const int nu = (int)(lh & 7u);
@@ -781,12 +737,12 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
                 P.leaf()[lane] = on ? (int)L.misc[16 + lane] : 0;
                 P.leaf()[7 + lane] = on ? (int)L.misc[24 + lane] : 0;
                 P.leaf()[14 + lane] = on ? (int)L.misc[32 + lane] : 0;
-                TM_REQ_ST(P.eval_obs()[lane], on ? (int)L.misc[24 + lane] : 0);
+                P.eval_obs()[lane] = on ? (int)L.misc[24 + lane] : 0;
             }
         }
         if (lane == 0) P.gs()[TM_GS_N_EXPAND] = GSV(gsv, TM_GS_N_EXPAND) + 1;
     } else {
-        if (lane < S.eval_slots) TM_REQ_ST(P.eval_obs()[lane], 0);
+        if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
     }
     if (lane == 0) {
         int32_t* gs = P.gs();
@@ -854,176 +810,8 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     // 32-bit offset; the inline form keeps the address arithmetic to one shift
     const uint64_t nq_base = (uint64_t)(uintptr_t)S.nq_table;
     const int nq_size = S.nq_size, max_trace = S.max_trace;
-    int n_miss = 0;
-#ifdef TM_PROF_WALK
-    long long prof_mem = 0;
-#define TM_WALK_PROF(SC, RN) { const long long tpa = __builtin_readcyclecounter(); asm volatile("" :: "v"(SC.x), "v"(RN.x)); \
-                               prof_mem += __builtin_readcyclecounter() - tpa; }
-#else
-#define TM_WALK_PROF(SC, RN)
-#endif
-#ifdef TM_EXP_NQ_CONST   /* timing experiment only (wrong results): what the table lookup's latency costs a level */
-#define TM_NQ_LOOKUP(CB, N) CB = 0x3f800000 | ((N) & 0xffff);
-#define TM_NQ_WAIT(CB, V)
-#elif defined(TM_NQ_SPLIT)   /* the table word is awaited after the part of the bound that does not need it */
-#define TM_NQ_LOOKUP(CB, N) asm volatile("s_load_dword %0, %1, %2" : "=s"(CB) : "s"(nq_base), "s"((N) << 2));
-#define TM_NQ_WAIT(CB, V) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(CB), "+v"(V));
-#else
+    int n_miss = 0, first_miss = -1;
 #define TM_NQ_LOOKUP(CB, N) asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(CB) : "s"(nq_base), "s"((N) << 2));
-#define TM_NQ_WAIT(CB, V)
-#endif
-#ifdef TM_WALK2
-    // EXPERIMENTAL (not the default build): two levels per memory round trip.  A record also holds the
-    // predicted GRANDchild (piece 0, word 3), so the record of level j+4 is requested as soon as the record of level j+2
-    // is here, and the statistics of level j+2's children with it: every load is issued two levels before its use and a
-    // level waits only for loads that are two levels old.  Six record quads r0..r5 (node ids q0..q5) and three statistics
-    // quads s0..s2 rotate through six instances of the level body: level j reads r[j] / s[j%3], assumes r[j+1] is its
-    // child, uses r[j+2] to issue s[(j+2)%3] and r[j+4].  A selection that differs from the assumed child rewrites the
-    // predictions it contradicts, leaves the steady loop and restarts the pipeline at the selected child.
-    // Loads and waits are inline assembly on PINNED register quads: the compiler's own s_waitcnt insertion waited for the
-    // newest load at every level (copies at register merges), and with unpinned assembly loads the allocator copied quads
-    // that were still in flight.  Loads return in order, so "at most N younger loads outstanding" = s_waitcnt vmcnt(N);
-    // stores issued in between only make a wait stricter.  A loaded quad is read only through the wait that names it.
-    typedef uint32_t tm_u32x4 __attribute__((ext_vector_type(4)));
-    auto mk_rs = [](const void* p_, size_t bytes) {
-        const uint64_t a_ = (uint64_t)p_;
-        tm_u32x4 v_;
-        v_.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a_);
-        v_.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a_ >> 32)) & 0xFFFFu;
-        v_.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bytes);
-        v_.w = 0x00020000u;
-        return v_;
-    };
-    const tm_u32x4 rec_q = mk_rs(P.rec(), P.n() * (TM_REC_DW * 4u)), stat_q = mk_rs(P.stat(), P.n() * 16u);
-#define TM_C_R0 "{v[88:91]}"
-#define TM_C_R1 "{v[92:95]}"
-#define TM_C_R2 "{v[96:99]}"
-#define TM_C_R3 "{v[100:103]}"
-#define TM_C_R4 "{v[104:107]}"
-#define TM_C_R5 "{v[108:111]}"
-#define TM_C_S0 "{v[112:115]}"
-#define TM_C_S1 "{v[116:119]}"
-#define TM_C_S2 "{v[120:123]}"
-#define TM_ALD(DST, CSTR, RS, OFF) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=" CSTR(DST) : "v"((uint32_t)(OFF)), "s"(RS));
-#define TM_AWAIT1(N, A, AC) asm volatile("s_waitcnt vmcnt(" #N ")" : "+" AC(A));
-#define TM_AWAIT2(N, A, AC, B, BC) asm volatile("s_waitcnt vmcnt(" #N ")" : "+" AC(A), "+" BC(B));
-    tm_u32x4 r0 = {0, 0, 0, 0}, r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, s0 = r0, s1 = r0, s2 = r0;
-    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
-    // every load in flight targets one of the nine quads: they stay reserved until this wait has been passed
-#define TM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" :: TM_C_R0(r0), TM_C_R1(r1), TM_C_R2(r2), TM_C_R3(r3), TM_C_R4(r4), \
-                                TM_C_R5(r5), TM_C_S0(s0), TM_C_S1(s1), TM_C_S2(s2) : "memory");
-    uint32_t prev_node = 0, prev_pp = 0;
-    int cur_node = idx;
-    // (re)start at node C: A = its record, B / C_ = predicted child / grandchild, D = B's predicted grandchild
-#define TM_WALK_START(C, RA, CA, QA, SA, CSA, RB, CB, QB, RC_, CC, QC, SB, CSB, RD, CD, QD)                             \
-    {                                                                                                                   \
-        QA = (C);                                                                                                       \
-        TM_DRAIN()                                          /* whatever the abandoned path still had in flight */       \
-        TM_ALD(RA, CA, rec_q, QA * (TM_REC_DW * 4u) + grp16)                                                            \
-        TM_AWAIT1(0, RA, CA)                                                                                            \
-        QB = rl_u32(RA.x, 56);                                                                                          \
-        QC = rl_u32(RA.w, 0);                                                                                           \
-        TM_ALD(SA, CSA, stat_q, RA.y * 16u)                                                                             \
-        TM_ALD(RB, CB, rec_q, QB * (TM_REC_DW * 4u) + grp16)                                                            \
-        TM_ALD(RC_, CC, rec_q, QC * (TM_REC_DW * 4u) + grp16)                                                           \
-        TM_AWAIT1(1, RB, CB)                                                                                            \
-        QD = rl_u32(RB.w, 0);                                                                                           \
-        TM_ALD(SB, CSB, stat_q, RB.y * 16u)                                                                             \
-        TM_ALD(RD, CD, rec_q, QD * (TM_REC_DW * 4u) + grp16)                                                            \
-    }
-#define TM_WALK_LEVEL(RC, QC, SC, CSC, Q1, R2, CR2, S2, CS2, R4, CR4, Q4)                                               \
-    {                                                                                                                   \
-        if (__builtin_expect((len & (TRACE_LDS - 1)) == 0, 0)) {                                                        \
-            if (len != 0) {      /* the LDS trace buffer is full */                                                     \
-                if (len >= max_trace) { overflow = true; walk_done = true; break; }                                     \
-                wave_sync(); flush_trace(len); wave_sync();                                                             \
-                if (lane == 56) tp = &L.tbuf[0];                                                                        \
-            }                                                                                                           \
-        }                                                                                                               \
-        *tp = make_uint4(RC.x, RC.y, RC.z, RC.w);   /* lane 56: piece 7 */                                              \
-        tp += tinc;                                                                                                     \
-        len += 1;                                                                                                       \
-        cur_node = (int)QC;                                                                                             \
-        const uint64_t onm = __builtin_amdgcn_ballot_w64(RC.x != 0u) & lanes_lt56;                                      \
-        if (onm == 0ull) { walk_done = true; break; } /* no children: a leaf */                                         \
-        /* the loads of two levels ahead */                                                                             \
-        TM_AWAIT2(2, SC, CSC, R2, CR2)   /* issued two levels ago; the previous level's pair may still be in flight */  \
-        Q4 = rl_u32(R2.w, 0);                                                                                           \
-        TM_ALD(S2, CS2, stat_q, R2.y * 16u)                                                                             \
-        TM_ALD(R4, CR4, rec_q, Q4 * (TM_REC_DW * 4u) + grp16)                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-        const int visit = (int)(SC.x & vmask);                                                                          \
-        const uint64_t lowmask = __builtin_amdgcn_ballot_w64(visit < low) & onm;                                        \
-        uint64_t selmask;                                                                                               \
-        if (__builtin_expect(lowmask != 0ull, 0)) {                                                                     \
-            uint64_t mm = lowmask & 0x0101010101010101ull;                                                              \
-            const int m = __popcll(mm);                                                                                 \
-            const uint32_t r = wave_rand_lds(L.misc, rng_pos, lane);                                                    \
-            const int kth = (int)(r % (uint32_t)m);                                                                     \
-            for (int t = 0; t < kth; ++t) mm &= mm - 1;                                                                 \
-            selmask = mm;                                                                                               \
-        } else {                                                                                                        \
-            const int n = (int)group_sum_u32((uint32_t)visit);                                                          \
-            int cbits;                                                                                                  \
-            if (__builtin_expect(n >= nq_size, 0)) {                                                                    \
-                cbits = __builtin_amdgcn_readfirstlane(__float_as_int(norm_quantile_dev((double)n)));                   \
-                nq_fallback += 1;                                                                                       \
-            } else {                                                                                                    \
-                TM_NQ_LOOKUP(cbits, n)                                                                                  \
-            }                                                                                                           \
-            const float own = rl_f32(__uint_as_float(RC.z), 56);     /* piece 7, word 2 (word 3 of piece 0 is taken) */ \
-            const float t1 = __uint_as_float(SC.y) + __uint_as_float(RC.z);                                             \
-            float val = t1 - own;                                                                                       \
-            TM_NQ_WAIT(cbits, val)                                                                                      \
-            const float prod = __int_as_float(cbits) * __uint_as_float(SC.w);                                           \
-            const float q = (val + prod) + 0.0f;                                                                        \
-            const uint32_t qb = __float_as_uint(q);                                                                     \
-            int key = (int)(qb ^ (((uint32_t)((int)qb >> 31)) >> 1));                                                   \
-            key = (q != q) ? nan_key : key;                                                                             \
-            key = (RC.x != 0u && lane < 56) ? key : (int)0x80000000;                                                    \
-            const int kmax = group_max_i32(key);                                                                        \
-            selmask = __builtin_amdgcn_ballot_w64(key == kmax);                                                         \
-        }                                                                                                               \
-        const uint32_t c = rl_u32(RC.x, __builtin_ctzll(selmask) & 56);                                                 \
-        const uint32_t my_p = rl_u32(RC.x, 56), my_pp = rl_u32(RC.w, 0);                                                \
-        /* keep the predictions true: this node's child, the previous node's grandchild */                             \
-        if (__builtin_expect(my_p != c, 0)) {                                                                           \
-            if (lane == 56) P.rec()[(size_t)QC * TM_REC_DW + TM_REC_PCHILD] = c;                                        \
-        }                                                                                                               \
-        if (__builtin_expect(prev_node != 0u && prev_pp != c, 0)) {                                                     \
-            if (lane == 0) P.rec()[(size_t)prev_node * TM_REC_DW + 3] = c;                                              \
-        }                                                                                                               \
-        prev_node = QC;                                                                                                 \
-        prev_pp = my_pp;                                                                                                \
-        if (__builtin_expect(c != Q1, 0)) {                                                                             \
-            /* not the child whose record was assumed: leave the steady loop, restart at the selected child */          \
-            restart_node = c;                                                                                           \
-            n_miss += 1;                                                                                                \
-            break;                                                                                                      \
-        }                                                                                                               \
-    }
-    uint32_t restart_node = (uint32_t)idx;
-    bool walk_done = false;
-    for (;;) {
-        // (re)start: always into the first rotation position
-        TM_WALK_START(restart_node, r0, TM_C_R0, q0, s0, TM_C_S0, r1, TM_C_R1, q1, r2, TM_C_R2, q2, s1, TM_C_S1, r3, TM_C_R3, q3)
-        for (;;) {
-            TM_WALK_LEVEL(r0, q0, s0, TM_C_S0, q1, r2, TM_C_R2, s2, TM_C_S2, r4, TM_C_R4, q4)
-            TM_WALK_LEVEL(r1, q1, s1, TM_C_S1, q2, r3, TM_C_R3, s0, TM_C_S0, r5, TM_C_R5, q5)
-            TM_WALK_LEVEL(r2, q2, s2, TM_C_S2, q3, r4, TM_C_R4, s1, TM_C_S1, r0, TM_C_R0, q0)
-            TM_WALK_LEVEL(r3, q3, s0, TM_C_S0, q4, r5, TM_C_R5, s2, TM_C_S2, r1, TM_C_R1, q1)
-            TM_WALK_LEVEL(r4, q4, s1, TM_C_S1, q5, r0, TM_C_R0, s0, TM_C_S0, r2, TM_C_R2, q2)
-            TM_WALK_LEVEL(r5, q5, s2, TM_C_S2, q0, r1, TM_C_R1, s1, TM_C_S1, r3, TM_C_R3, q3)
-        }
-        if (walk_done) break;
-    }
-    TM_DRAIN()      // the loads of the last two levels are still in flight: nothing may reuse their registers before this
-#undef TM_DRAIN
-#undef TM_WALK_START
-#undef TM_ALD
-#undef TM_AWAIT1
-#undef TM_AWAIT2
-#else
     // three record register sets and two statistics sets rotate through the roles (current node, predicted child,
     // predicted grandchild) / (this level, next level): the loop body is instantiated six times instead of moving
     // eleven registers per level.  p0..p2 = predicted child (piece 7, word 0) of the node held in r0..r2.
@@ -1047,7 +835,6 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         len += 1;                                                                                                       \
         const uint64_t onm = __builtin_amdgcn_ballot_w64(RC.x != 0u) & lanes_lt56;                                      \
         if (onm == 0ull) break;                       /* no children: a leaf */                                         \
-        TM_WALK_PROF(SC, RN)                                                                                            \
         /* the next level's round of loads, on the assumption that the predicted child is the one */                   \
         PN = rl_u32(RN.x, 56);                                                                                          \
         SN = buf_ld16(stat_rs, RN.y * 16u);                                                                             \
@@ -1078,7 +865,6 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
             }                                                                                                           \
             const float t1 = __uint_as_float(SC.y) + __uint_as_float(RC.z);                                             \
             float val = t1 - __uint_as_float(RC.w);                                                                     \
-            TM_NQ_WAIT(cbits, val)                                                                                      \
             const float prod = __int_as_float(cbits) * __uint_as_float(SC.w);                                           \
             const float q = (val + prod) + 0.0f;         /* -0 becomes +0 (the float compare treats them as equal) */   \
             /* first-max argmax with the reference's scan semantics (max_q = q_0; i >= 1 replaces only if q_i > max_q): \
@@ -1100,6 +886,7 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
             PN = rl_u32(RN.x, 56);                                                                                      \
             SN = buf_ld16(stat_rs, RN.y * 16u);                                                                         \
             RNN = buf_ld16(rec_rs, PN * (TM_REC_DW * 4u) + grp16);                                                      \
+            if (n_miss == 0) first_miss = len - 1;                                                                      \
             n_miss += 1;                                                                                                \
         }                                                                                                               \
         cur_node = (int)c;                                                                                              \
@@ -1112,11 +899,8 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         TM_WALK_LEVEL(r1, p1, s0, r2, p2, s1, r0)
         TM_WALK_LEVEL(r2, p2, s1, r0, p0, s0, r1)
     }
-#endif
 #undef TM_WALK_LEVEL
-#undef TM_WALK_PROF
 #undef TM_NQ_LOOKUP
-#undef TM_NQ_WAIT
     idx = cur_node;
     wave_sync();
     // piece 7 of the node the walk ended at = the last trace entry (on a trace overflow the node is not recorded: it is
@@ -1168,9 +952,8 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         if (nq_fallback) gs[TM_GS_N_NQ_FALLBACK] = GSV(gsv, TM_GS_N_NQ_FALLBACK) + nq_fallback;
         gs[TM_GS_SIM_STARTED] = GSV(gsv, TM_GS_SIM_STARTED) + 1;
         gs[TM_GS_N_WALK_MISS] = GSV(gsv, TM_GS_N_WALK_MISS) + n_miss;
-#ifdef TM_PROF_WALK
-        gs[TM_GS_CYC_WALK_MEM] = (int)prof_mem;
-#endif
+        gs[TM_GS_FIRST_MISS] = first_miss < 0 ? len : first_miss;
+        gs[TM_GS_PREFIX_SUM] = GSV(gsv, TM_GS_PREFIX_SUM) + (first_miss < 0 ? len : first_miss);
     }
     if (rng_pos != rng_pos0) {
         if (lane < 32) S.rng[(size_t)g * 32 + lane] = rng_keep;
@@ -1463,7 +1246,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         // this game is collecting garbage: one slice per launch (S.gc_slice_cycles; 0 = to completion), no simulation
         // (catch-up launches pass TM_SIM_GC_FULL: only laggards are left, nobody is held up by a collection run to its end)
         const bool sliced = S.gc_slice_cycles > 0 && !(flags & TM_SIM_GC_FULL);
-        if (!gc_run(S, P, g, lane, sliced ? (long long)S.gc_slice_cycles : -1)) { TM_PUBLISH() return; }
+        if (!gc_run(S, P, g, lane, sliced ? (long long)S.gc_slice_cycles : -1)) return;
         gsv = gs[lane];
     }
     const int pend = GSV(gsv, TM_GS_PENDING);
@@ -1473,10 +1256,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         const uint32_t self_o = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_OBS];
         const uint32_t self_sc = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_SCORE];
         wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc, gsv);
-        TM_PUBLISH()
         return;
     }
-#ifndef TM_NO_SETPRIO
     // A launch lasts as long as its slowest wave, and a wave's time is proportional to the length of its game's walk (mean
     // 69 nodes, maximum 160 at 4096 games).  The games with the longest walks get issue priority over the three other
     // waves of their SIMD (static priority: the loser pays little, it was going to wait for this wave anyway).
@@ -1486,7 +1267,6 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         else if (last_len >= 88) __builtin_amdgcn_s_setprio(2);
         else if (last_len >= 72) __builtin_amdgcn_s_setprio(1);
     }
-#endif
     const long long t0 = __builtin_readcyclecounter();
     if ((flags & TM_SIM_BACKUP) && pend == 1) {
         wave_sim_back(S, P, L, lane, gsv);
@@ -1497,8 +1277,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     // the per-move quota (tm_move_begin): games that lost launches to a collection catch up in extra launches
     if ((flags & TM_SIM_FRONT) && GSV(gsv, TM_GS_SIM_STARTED) < GSV(gsv, TM_GS_SIM_TARGET))
         wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane, gsv);
-    else if (lane < S.eval_slots) TM_REQ_ST(P.eval_obs()[lane], 0);   // nothing started: no request (the evaluator skips empty slots)
-    TM_PUBLISH()
+    else if (lane < S.eval_slots) P.eval_obs()[lane] = 0;   // nothing started: no request (the evaluator skips empty slots)
 }
 
 // per-move simulation quota (TreeAgent.play: self.mcts(self.root, self.sims), agents/agent.py:147-150)

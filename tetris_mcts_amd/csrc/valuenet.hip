@@ -212,11 +212,6 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, const in
 #define TM_CONV_WAVES 1
 #endif
 #include "valuenet_conv.inc"
-#ifdef TM_OVERLAP
-#define TM_CONV_POLLED
-#include "valuenet_conv.inc"
-#undef TM_CONV_POLLED
-#endif
 
 // fc1 (1792 -> 256) + ReLU on v_mfma_f32_16x16x4_f32 (D[16x16] += A[16x4] B[4x16]; lane l: A[i=l&15][k=l>>4],
 // B[k=l>>4][j=l&15], D[i=(l>>4)*4+r][j=l&15]; per output a k-ordered fma chain, 4 terms per instruction).
@@ -362,37 +357,6 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, v, var, n, eval_obs);
     return (int)hipGetLastError();
 }
-
-#ifdef TM_OVERLAP
-// EXPERIMENTAL (-DTM_OVERLAP builds only, called by search.hip): the request form of the forward pass launched BESIDE the
-// tree kernel of the same simulation on another stream.  One convolution workgroup per CU (the tree kernel's workgroups
-// share the CU); a wave takes a slot when the slot's game has published `seq` (tree.hip, end of k_sim_step).
-int tm_valuenet_forward_requests_polled(const float* P, const float* prepared, const tm_store* s, float* scratch, int seq,
-                                        void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    const int n = s->n_games * s->eval_slots;
-    if (n <= 0) return 0;
-    constexpr int SS = TM_VALUENET_SCRATCH_MFMA;
-    static bool attr_set = false;
-    const int lds = 4 * WAVE_LDS * (int)sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_vn_conv_polled),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    int blocks = (n + 3) / 4;
-    if (blocks > 256) blocks = 256;
-    const long long spin_cycles = 50000000ll;      // about 20 ms: a collection run to its end takes 3
-    hipLaunchKernelGGL(k_vn_conv_polled, dim3(blocks), dim3(256), lds, stream, P, prepared, (const int8_t*)nullptr, s->obs_key,
-                       s->eval_obs, s->eval_slots, s->max_nodes, n, scratch, SS, s->gs, seq, spin_cycles);
-    hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(512), 0, stream, P, prepared, scratch, SS, n, scratch + A3, SS,
-                       s->eval_obs);
-    hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, s->eval_v, s->eval_var, n,
-                       s->eval_obs);
-    return (int)hipGetLastError();
-}
-#endif
 
 // matrix-core path; prepared: tm_valuenet_prepare output; scratch: n x TM_VALUENET_SCRATCH_MFMA floats
 int tm_valuenet_forward(const float* P, const float* prepared, const int8_t* states, int n, float* v, float* var,
