@@ -224,7 +224,7 @@ def main():
                "dropped_tuples": int(dropped), "trees_restarted_pool_outgrown": int(pool_resets)},
         "store_gib_per_gpu": S.nbytes() / 2**30,
         "last_sim_phase_kcycles": {k: float(S.t["gs"][:, st.GS[k]].float().mean().item()) / 1e3
-                                   for k in ("CYC_BACK", "CYC_SELECT", "CYC_EXPAND", "CYC_WALK_MEM", "TRACE_LEN")},
+                                   for k in ("CYC_BACK", "CYC_SELECT", "CYC_VERIFY", "CYC_EXPAND", "FIRST_MISS", "TRACE_LEN")},
     }
     if args.online:
         out["exchange"] = {"what": "all-gather of the (packed observation, value, variance, visit) tuples harvested at GC, "

@@ -51,7 +51,7 @@ enum {
     TM_GS_CYC_TAIL,      /* duration of the last GC in units of 16 cycles; +1: nodes reachable at that GC */
     TM_GS_N_DROPPED = 25, /* replay tuples a GC could not store because the harvest buffer was full (drain it more often) */
     TM_GS_LOW_NODE = 26, TM_GS_LOW_OBS,  /* lowest node / observation index ever allocated (GC skips untouched entries) */
-    TM_GS_FIRST_MISS = 28, /* tree level at which the last walk first left its node's predicted child (= its length if it never did) */
+    TM_GS_FIRST_MISS = 28, /* levels of the last walk that were taken over from the walk before it (verified in parallel, tree.hip) */
     TM_GS_PREFIX_SUM,      /* sum of TM_GS_FIRST_MISS over all simulations */
     /* resumable garbage collection (a game that collects does not simulate in that launch) */
     TM_GS_GC_PHASE = 32, /* 0 none, 1 requested, 2 marking, 3 clearing the tables, 4 sweeping, 5 re-inserting */
@@ -62,7 +62,7 @@ enum {
     /* per-move simulation quota: tm_move_begin adds `sims` to the target; a launch starts a simulation for a game only
        while started < target, so games that lost launches to a collection catch up in extra launches (tm_sims_remaining) */
     TM_GS_SIM_TARGET = 40, TM_GS_SIM_STARTED,
-    TM_GS_RESERVED42,
+    TM_GS_CYC_VERIFY,    /* shader cycles of the last walk's parallel prefix verification (part of TM_GS_CYC_SELECT) */
     TM_GS_N_WALK_MISS,   /* tree levels at which the walk descended into another child than the predicted one (all simulations) */
     TM_GS_POOL_FULL      /* the reachable tree fills the pool (TM_ERR_POOL): no collection is attempted until the root moves */
 };
@@ -112,7 +112,7 @@ typedef struct tm_store {
     uint32_t *rng;        /* [G][32] glibc rand() state (31 words) per game (core.h:62,76) */
     uint32_t *env_game;   /* [G][16] the real games */
     int32_t *env_line_stats; /* [G][4] */
-    uint32_t *trace;      /* [G][max_trace][4] piece 7 of the record of every node of the walk in flight (word 1 observation, word 2 score bits); max_trace % 64 == 0 */
+    uint32_t *trace;      /* [G][max_trace][4] the last walk: per level (node, its observation, its score bits, its record's header) */
     int32_t *leaf;        /* [G][32] unique children of the leaf: node[7], obs[7], score bits[7], end[7] */
     int32_t *eval_obs;    /* [G*eval_slots] observation index inside the game's pool, 0 = unused slot */
     float *eval_v;        /* [G*eval_slots] evaluator outputs */

@@ -36,6 +36,13 @@ for m in range(a.moves):
                frac_first_miss_ge_90pct=float((fm >= 0.9 * ln - 1).mean()),
                top1pct_remaining_levels=float((ln[top] - fm[top]).mean()), mean_remaining_levels=float((ln - fm).mean()),
                max_remaining_levels=int((ln - fm).max()))
+    cyc = {k: gs[:, i].astype(np.int64) for k, i in (("back", 20), ("select", 21), ("expand", 22), ("verify", 42))}
+    tot = cyc["back"] + cyc["select"] + cyc["expand"]
+    slow = np.argsort(-tot)[:8]
+    rec["kcycles_mean"] = {k: float(v.mean()) / 1e3 for k, v in cyc.items()}
+    rec["kcycles_p99"] = {k: float(np.percentile(v, 99)) / 1e3 for k, v in cyc.items()}
+    rec["kcycles_total_mean_p99_max"] = [float(tot.mean()) / 1e3, float(np.percentile(tot, 99)) / 1e3, float(tot.max()) / 1e3]
+    rec["slowest_games"] = [dict(g=int(g), len=int(ln[g]), k0=int(fm[g]), **{k: int(v[g]) // 1000 for k, v in cyc.items()}) for g in slow]
     out.append(rec)
     print(json.dumps(rec), flush=True)
     game.play(act)

@@ -798,7 +798,7 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     // store theirs to a dummy slot, so the walk needs no exec masking for it
     uint4* tp = (lane == 56) ? &L.tbuf[0] : &L.tdummy[lane];
     const int tinc = (lane == 56) ? 1 : 0;
-    int flushed = 0;
+    int flushed = 0;          // entries [0, flushed) of the trace are in global memory (set to the verified prefix below)
     auto flush_trace = [&](int upto) {   // entries [flushed, upto) from LDS to global, coalesced
         for (int base = flushed; base < upto; base += 64) {
             int i = base + lane;
@@ -810,8 +810,98 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     // 32-bit offset; the inline form keeps the address arithmetic to one shift
     const uint64_t nq_base = (uint64_t)(uintptr_t)S.nq_table;
     const int nq_size = S.nq_size, max_trace = S.max_trace;
-    int n_miss = 0, first_miss = -1;
+    int n_miss = 0;
 #define TM_NQ_LOOKUP(CB, N) asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(CB) : "s"(nq_base), "s"((N) << 2));
+    // ---- the part of the previous walk that is still the selected path, verified in parallel ----
+    // Nine levels out of ten of a walk repeat the game's previous walk (profiles/r03_walk_prefix_before.jsonl: 92 % of all
+    // levels; five levels remain after the first difference, for the longest walks as for the mean).  The previous walk is
+    // in the trace buffer (word 0 of an entry = the node), its nodes' records are immutable once expanded, and whether
+    // level i still selects path[i + 1] depends only on the children's CURRENT statistics - not on the levels above it.
+    // So the levels are checked independently, eight at a time (one 8-lane group per level, lane t = unique child t),
+    // four such chunks per round of loads: records, then statistics, then the norm_quantile words, all in flight together,
+    // instead of one dependent round trip per level.  The arithmetic is policy_clt's, operation for operation; a level
+    // with an under-visited child (check_low would draw from rand()), a table miss or another selection ends the prefix,
+    // and the pipelined serial walk below takes over at that level (its entries [0, k0) of the trace are already in place).
+    int k0 = 0;
+    {
+        const int prev_len = GSV(gsv, TM_GS_TRACE_LEN);
+        const uint32_t* tr = P.trace();
+        const int nver = prev_len - 1;          // levels 0 .. nver - 1 have a recorded successor
+        if (nver > 0 && tr[0] == (uint32_t)idx) {
+            const int t8 = lane & 7;
+            const uint32_t t16 = (uint32_t)t8 * 16u;
+            const uint32_t vm8 = t8 < 7 ? 0x7FFFFFFFu : 0u;
+            const int nan8 = t8 == 0 ? 0x7FFFFFFF : (int)0x80000000;
+            const float* nqt = S.nq_table;
+            int base = 0;
+            bool stop = false;
+            uint32_t pa = 0, pb = 0;
+            while (!stop) {
+                // path[base + lane] and path[base + lane + 1]: 64 levels per coalesced load
+                const int li = base + lane;
+                pa = li < prev_len ? tr[(size_t)li * 4] : 0u;
+                pb = li + 1 < prev_len ? tr[(size_t)(li + 1) * 4] : 0u;
+                k0 = min(nver, base + 64);
+                for (int c0 = 0; c0 < 64 && base + c0 < nver; c0 += 32) {
+                    uint4 rc[4], sc[4];
+                    uint32_t ex[4], nsum[4];
+                    float cb[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int src = (c0 + 8 * c + grp) * 4;           // the lane that holds this group's level
+                        const uint32_t node = bperm_u32(src, pa);
+                        ex[c] = bperm_u32(src, pb);
+                        rc[c] = buf_ld16(rec_rs, node * (TM_REC_DW * 4u) + t16);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sc[c] = buf_ld16(stat_rs, rc[c].y * 16u);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        uint32_t n = sc[c].x & vm8;                     // empty slots read the null observation: 0 visits
+                        n += dpp_x1(n); n += dpp_x2(n); n += dpp_hm(n);
+                        nsum[c] = n;
+                        cb[c] = nqt[min(n, (uint32_t)(nq_size - 1))];
+                    }
+                    uint64_t bad[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool act = base + c0 + 8 * c + grp < nver;
+                        const bool exists = rc[c].x != 0u && t8 < 7;
+                        const int visit = (int)(sc[c].x & vm8);
+                        const uint64_t lowb = __builtin_amdgcn_ballot_w64(exists && visit < low);
+                        const bool low_any = ((lowb >> (grp * 8)) & 0xFFull) != 0ull;
+                        const float t1 = __uint_as_float(sc[c].y) + __uint_as_float(rc[c].z);
+                        const float val = t1 - __uint_as_float(rc[c].w);
+                        const float prod = cb[c] * __uint_as_float(sc[c].w);
+                        const float q = (val + prod) + 0.0f;
+                        const uint32_t qb = __float_as_uint(q);
+                        int key = (int)(qb ^ (((uint32_t)((int)qb >> 31)) >> 1));
+                        key = (q != q) ? nan8 : key;
+                        key = exists ? key : (int)0x80000000;
+                        int km = key;
+                        km = max(km, (int)dpp_x1((uint32_t)km));
+                        km = max(km, (int)dpp_x2((uint32_t)km));
+                        km = max(km, (int)dpp_hm((uint32_t)km));
+                        const uint64_t eq = __builtin_amdgcn_ballot_w64(key == km);
+                        const int slot = __builtin_ctz((uint32_t)((eq >> (grp * 8)) & 0xFFull) | 0x100u);
+                        const uint32_t csel = bperm_u32(((lane & ~7) + (slot & 7)) * 4, rc[c].x);
+                        const bool ok = !act || (csel == ex[c] && !low_any && nsum[c] < (uint32_t)nq_size);
+                        bad[c] = ~__builtin_amdgcn_ballot_w64(ok) & 0x0101010101010101ull;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (!stop && bad[c] != 0ull) { k0 = base + c0 + 8 * c + (__builtin_ctzll(bad[c]) >> 3); stop = true; }
+                    if (stop) break;
+                }
+                if (stop || base + 64 >= nver) break;
+                base += 64;
+            }
+            // the node of level k0: path[k0]
+            idx = (int)(k0 == base ? rl_u32(pa, 0) : rl_u32(pb, k0 - base - 1));
+            len = k0;
+        }
+    }
+    const long long tc_ver = __builtin_readcyclecounter();
     // three record register sets and two statistics sets rotate through the roles (current node, predicted child,
     // predicted grandchild) / (this level, next level): the loop body is instantiated six times instead of moving
     // eleven registers per level.  p0..p2 = predicted child (piece 7, word 0) of the node held in r0..r2.
@@ -821,18 +911,24 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     r1 = buf_ld16(rec_rs, p0 * (TM_REC_DW * 4u) + grp16);
     r2 = r1;
     int cur_node = idx;
+    flushed = len;
+    int room = min(TRACE_LDS, max_trace - len);
 #define TM_WALK_LEVEL(RC, PC, SC, RN, PN, SN, RNN)                                                                      \
     {                                                                                                                   \
-        if (__builtin_expect((len & (TRACE_LDS - 1)) == 0, 0)) {                                                        \
-            if (len != 0) {      /* the LDS trace buffer is full */                                                     \
-                if (len >= max_trace) { overflow = true; break; }                                                       \
-                wave_sync(); flush_trace(len); wave_sync();                                                             \
-                if (lane == 56) tp = &L.tbuf[0];                                                                        \
-            }                                                                                                           \
+        if (__builtin_expect(room == 0, 0)) {     /* the LDS trace buffer is full, or the trace is */                   \
+            if (len >= max_trace) { overflow = true; break; }                                                           \
+            wave_sync(); flush_trace(len); wave_sync();                                                                 \
+            if (lane == 56) tp = &L.tbuf[0];                                                                            \
+            room = min(TRACE_LDS, max_trace - len);                                                                     \
         }                                                                                                               \
-        *tp = RC;                /* lane 56 holds piece 7: (predicted child, own observation, own score, header) */     \
+        {   /* lane 56 holds piece 7: the entry is (this node, own observation, own score, header) */                   \
+            uint4 te_ = RC;                                                                                             \
+            te_.x = (uint32_t)cur_node;                                                                                 \
+            *tp = te_;                                                                                                  \
+        }                                                                                                               \
         tp += tinc;                                                                                                     \
         len += 1;                                                                                                       \
+        room -= 1;                                                                                                      \
         const uint64_t onm = __builtin_amdgcn_ballot_w64(RC.x != 0u) & lanes_lt56;                                      \
         if (onm == 0ull) break;                       /* no children: a leaf */                                         \
         /* the next level's round of loads, on the assumption that the predicted child is the one */                   \
@@ -886,7 +982,6 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
             PN = rl_u32(RN.x, 56);                                                                                      \
             SN = buf_ld16(stat_rs, RN.y * 16u);                                                                         \
             RNN = buf_ld16(rec_rs, PN * (TM_REC_DW * 4u) + grp16);                                                      \
-            if (n_miss == 0) first_miss = len - 1;                                                                      \
             n_miss += 1;                                                                                                \
         }                                                                                                               \
         cur_node = (int)c;                                                                                              \
@@ -943,6 +1038,7 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
     if (lane == 0) {
         int32_t* gs = P.gs();
         gs[TM_GS_CYC_SELECT] = (int)(tc_sel - tc_start);
+        gs[TM_GS_CYC_VERIFY] = (int)(tc_ver - tc_start);
         gs[TM_GS_TRACE_LEN] = len;
         gs[TM_GS_LEAF] = leaf;
         gs[TM_GS_LEAF_END] = leaf_end | (overflow ? 1 : 0);
@@ -952,8 +1048,8 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         if (nq_fallback) gs[TM_GS_N_NQ_FALLBACK] = GSV(gsv, TM_GS_N_NQ_FALLBACK) + nq_fallback;
         gs[TM_GS_SIM_STARTED] = GSV(gsv, TM_GS_SIM_STARTED) + 1;
         gs[TM_GS_N_WALK_MISS] = GSV(gsv, TM_GS_N_WALK_MISS) + n_miss;
-        gs[TM_GS_FIRST_MISS] = first_miss < 0 ? len : first_miss;
-        gs[TM_GS_PREFIX_SUM] = GSV(gsv, TM_GS_PREFIX_SUM) + (first_miss < 0 ? len : first_miss);
+        gs[TM_GS_FIRST_MISS] = k0;
+        gs[TM_GS_PREFIX_SUM] = GSV(gsv, TM_GS_PREFIX_SUM) + k0;
     }
     if (rng_pos != rng_pos0) {
         if (lane < 32) S.rng[(size_t)g * 32 + lane] = rng_keep;
@@ -1257,15 +1353,6 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         const uint32_t self_sc = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_SCORE];
         wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc, gsv);
         return;
-    }
-    // A launch lasts as long as its slowest wave, and a wave's time is proportional to the length of its game's walk (mean
-    // 69 nodes, maximum 160 at 4096 games).  The games with the longest walks get issue priority over the three other
-    // waves of their SIMD (static priority: the loser pays little, it was going to wait for this wave anyway).
-    {
-        const int last_len = GSV(gsv, TM_GS_TRACE_LEN);
-        if (last_len >= 112) __builtin_amdgcn_s_setprio(3);
-        else if (last_len >= 88) __builtin_amdgcn_s_setprio(2);
-        else if (last_len >= 72) __builtin_amdgcn_s_setprio(1);
     }
     const long long t0 = __builtin_readcyclecounter();
     if ((flags & TM_SIM_BACKUP) && pend == 1) {

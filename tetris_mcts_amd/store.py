@@ -15,7 +15,7 @@ KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA, 
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18, MAX_TRACE=19, N_DROPPED=25,
           CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_SLICES=38,
-          SIM_TARGET=40, SIM_STARTED=41, CYC_WALK_MEM=42, N_WALK_MISS=43, POOL_FULL=44)
+          SIM_TARGET=40, SIM_STARTED=41, CYC_VERIFY=42, FIRST_MISS=28, PREFIX_SUM=29, N_WALK_MISS=43, POOL_FULL=44)
 
 _nq_cache = {}
 
