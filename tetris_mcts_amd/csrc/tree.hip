@@ -13,6 +13,7 @@
 // of the children's records).  The raw per-action child indices live in a separate 32-byte row (GC, root statistics).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <atomic>
 #include "engine.h"
 #include "../../include/tetris_mcts_hip.h"
 
@@ -260,8 +261,7 @@ __device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, u
     }
 }
 
-__device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane);
-__device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, int lane, long long budget);
+__device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, int lane);
 
 // `gsv`: the wave's snapshot of the game's control block (word i in lane i), valid when nothing in this launch has changed
 // the free-list words yet (the expansion's first attempt); has_gsv = false: read them from memory (sequential retries,
@@ -400,7 +400,8 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
 // redone - the successors already inserted are transposition hits, the others pop from the rebuilt free list in order.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
-                                   uint32_t self_sc /* float bits of the leaf's own score */, uint32_t& hdr_out, int gsv) {
+                                   uint32_t self_sc /* float bits of the leaf's own score */, uint32_t& hdr_out, int gsv,
+                                   int gc_req_word /* (launch << 4) | GC_REQ: what a collection request looks like */) {
     if (lane < GAME_DW) L.slots[7][lane] = P.game()[(size_t)leaf * GAME_DW + lane];
     wave_sync();
     for (int t = lane; t < 7 * GAME_DW; t += 64) L.slots[t >> 4][t & 15] = L.slots[7][t & 15];
@@ -432,7 +433,7 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
             if (i1 < 0) {
                 if (!P.gs()[TM_GS_GC_RETRY] && !P.gs()[TM_GS_POOL_FULL]) {
                     if (lane < GAME_DW) L.slots[0][lane] = keep;
-                    if (lane == 0) { P.gs()[TM_GS_GC_PHASE] = 1; P.gs()[TM_GS_GC_RETRY] = 1; }
+                    if (lane == 0) { P.gs()[TM_GS_GC_PHASE] = gc_req_word; P.gs()[TM_GS_GC_RETRY] = 1; }
                     wave_sync();
                     return false;
                 }
@@ -711,13 +712,13 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
 // ---------------------------------------------------------------------------------------------------
 template <bool VANILLA>
 __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
-                                                  int leaf_end, uint32_t self_o, uint32_t self_sc, int gsv) {
+                                                  int leaf_end, uint32_t self_o, uint32_t self_sc, int gsv, int gc_req_word) {
     const long long tc0 = __builtin_readcyclecounter();
     const int kind = S.kind;
     int k_eval = 0;
     if (!leaf_end) {
         uint32_t lh;
-        if (!wave_expand(S, P, L, g, lane, leaf, self_sc, lh, gsv)) {
+        if (!wave_expand(S, P, L, g, lane, leaf, self_sc, lh, gsv, gc_req_word)) {
             if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
             if (lane == 0) P.gs()[TM_GS_PENDING] = 2;
             return;
@@ -758,7 +759,8 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
 // the front half: select_trace_obs (core.h:167-224), then expansion and evaluation requests
 // ---------------------------------------------------------------------------------------------------
 template <bool VANILLA>
-__device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, int g, int lane, int gsv) {
+__device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, int g, int lane, int gsv,
+                                               int gc_req_word) {
     const long long tc_start = __builtin_readcyclecounter();
     if (lane < 32) L.misc[lane] = S.rng[(size_t)g * 32 + lane];      // glibc rand() state (31 words), used by check_low only
     wave_sync();
@@ -827,7 +829,9 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         const int prev_len = GSV(gsv, TM_GS_TRACE_LEN);
         const uint32_t* tr = P.trace();
         const int nver = prev_len - 1;          // levels 0 .. nver - 1 have a recorded successor
-        if (nver > 0 && tr[0] == (uint32_t)idx) {
+        // (word 0 of entry 0 = the root of the previous walk: after update_root the path does not start at this root)
+        uint32_t pa = nver > 0 && lane < prev_len ? tr[(size_t)lane * 4] : 0u;
+        if (nver > 0 && rl_u32(pa, 0) == (uint32_t)idx) {
             const int t8 = lane & 7;
             const uint32_t t16 = (uint32_t)t8 * 16u;
             const uint32_t vm8 = t8 < 7 ? 0x7FFFFFFFu : 0u;
@@ -835,11 +839,11 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
             const float* nqt = S.nq_table;
             int base = 0;
             bool stop = false;
-            uint32_t pa = 0, pb = 0;
+            uint32_t pb = 0;
             while (!stop) {
                 // path[base + lane] and path[base + lane + 1]: 64 levels per coalesced load
                 const int li = base + lane;
-                pa = li < prev_len ? tr[(size_t)li * 4] : 0u;
+                if (base != 0) pa = li < prev_len ? tr[(size_t)li * 4] : 0u;
                 pb = li + 1 < prev_len ? tr[(size_t)(li + 1) * 4] : 0u;
                 k0 = min(nver, base + 64);
                 for (int c0 = 0; c0 < 64 && base + c0 < nver; c0 += 32) {
@@ -854,7 +858,7 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
                         rc[c] = buf_ld16(rec_rs, node * (TM_REC_DW * 4u) + t16);
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) sc[c] = buf_ld16(stat_rs, rc[c].y * 16u);
+                    for (int c = 0; c < 4; ++c) sc[c] = buf_ld16(stat_rs, t8 < 7 ? rc[c].y * 16u : 0u);   // lane 7 of a group holds the node's own piece
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         uint32_t n = sc[c].x & vm8;                     // empty slots read the null observation: 0 visits
@@ -1055,14 +1059,9 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         if (lane < 32) S.rng[(size_t)g * 32 + lane] = rng_keep;
         if (lane == 0) P.gs()[TM_GS_RNG_POS] = rng_pos;
     }
-    wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end | (overflow ? 1 : 0), self_o, self_sc, gsv);
+    wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end | (overflow ? 1 : 0), self_o, self_sc, gsv, gc_req_word);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// GC (agents/agent.py:206-257, ValueSim.py:101-159): reachable set from the root, free lists rebuilt in
-// ascending order, freed nodes / observations cleared, replay tuples harvested, tables rebuilt.
-// Executed by the game's own wave at the exact pop where the reference runs it.
-// ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool bit_test_set(uint8_t* bm, uint32_t i) {
     uint32_t* w = reinterpret_cast<uint32_t*>(bm) + (i >> 5);
     uint32_t m = 1u << (i & 31);
@@ -1073,94 +1072,178 @@ __device__ __forceinline__ bool bit_test(const uint8_t* bm, uint32_t i) {
     return (reinterpret_cast<const uint32_t*>(bm)[i >> 5] >> (i & 31)) & 1u;
 }
 
-// The collection is RESUMABLE: it runs in slices of about `budget` shader cycles (budget < 0: to completion), its
-// progress lives in the game's control block (TM_GS_GC_*), and a game that is collecting simply does not simulate in
-// that launch - the other 4095 games of the launch are not held up by one wavefront sweeping a 100 000-entry pool
-// (3 ms against a 0.1 ms launch).  The simulation that hit the empty pool is suspended in its expansion
-// (TM_GS_PENDING == 2) and redone when the collection is complete; the order of events inside the game is exactly
-// the reference's.  Returns true when the collection is complete.
-__device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, int lane, long long budget) {
+// ---------------------------------------------------------------------------------------------------
+// GC (agents/agent.py:206-257, ValueSim.py:101-159): reachable set from the root, free lists rebuilt in
+// ascending order, freed observations cleared, replay tuples harvested, tables rebuilt.
+//
+// A collection is the work of a GROUP of T threads: a whole 256-thread workgroup (the collector workgroups that
+// k_sim_step carries beside its simulation workgroups; tm_tree_remove_nodes), or one wave where a kernel's waves own
+// different games (update_root's exhausting pop, the single-call entry points).  It is RESUMABLE: it runs in slices up
+// to a deadline (shader clock; none: to completion), its progress lives in the game's control block (TM_GS_GC_*), and
+// a game that is collecting simply does not simulate - the launch is never held up by the sweep of a 100 000-entry
+// pool.  The simulation that hit the empty pool is suspended in its expansion (TM_GS_PENDING == 2) and redone when the
+// collection is complete; the order of events inside the game is exactly the reference's.
+//
+// Hand-over between a game's simulation wave and a collector workgroup happens at kernel boundaries only (different
+// CUs, different L2s: nothing written in a launch is read by the other side in the same launch).  The phase word
+// carries the launch number for that: a request is (launch << 4) | 1 and is picked up by the collectors of LATER
+// launches; a finished collection leaves (launch << 4) | 7 and the game's wave resumes in a LATER launch.
+// ---------------------------------------------------------------------------------------------------
+constexpr int GC_REQ = 1, GC_MARK = 2, GC_CLEAR = 3, GC_SWEEP = 4, GC_NODES = 5, GC_OBS = 6, GC_DONE = 7;
+constexpr int GC_BLOCKS_MAX = 32;   // collector workgroups of a k_sim_step launch (each serves a contiguous range of games)
+__host__ __device__ inline int gc_blocks(int n_games) {
+    const int sim_blocks = (n_games + WPB - 1) / WPB;
+    return sim_blocks < GC_BLOCKS_MAX ? sim_blocks : GC_BLOCKS_MAX;
+}
+
+template <int T> struct Grp {
+    static constexpr int NW = T / 64;
+    // all stores of the group so far are visible to all of its threads (same CU: workgroup scope)
+    static __device__ __forceinline__ void sync() {
+        if constexpr (T == 64) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    }
+    // exclusive prefix sum of v over the group's threads in thread order; total to every thread.  sm: NW + 1 ints
+    static __device__ __forceinline__ int exscan(int v, int tid, int* sm, int& total) {
+        const int lane = tid & 63;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if constexpr (T == 64) {
+            total = __shfl(incl, 63, 64);
+            return incl - v;
+        } else {
+            const int w = tid >> 6;
+            __syncthreads();               // the previous use of sm is over
+            if (lane == 63) sm[w] = incl;
+            __syncthreads();
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { const int x = sm[i]; off += i < w ? x : 0; tot += x; }
+            total = tot;
+            return off + incl - v;
+        }
+    }
+    // thread 0's value to every thread
+    static __device__ __forceinline__ int bcast(int v, int tid, int* sm) {
+        if constexpr (T == 64) return __shfl(v, 0, 64);
+        else {
+            __syncthreads();
+            if (tid == 0) sm[NW] = v;
+            __syncthreads();
+            return sm[NW];
+        }
+    }
+};
+
+// Returns true when the collection is complete.  deadline < 0: no deadline.  done_word: what the phase word becomes at the
+// end (0, or (launch << 4) | GC_DONE for a collector workgroup).  sm: Grp<T>::NW + 1 ints of LDS (unused for T == 64).
+template <int T>
+__device__ __forceinline__ bool gc_collect(const tm_store& S, const GP& P, int g, int tid, long long deadline, int* sm, int done_word) {
+    typedef Grp<T> G_;
+    constexpr int U = 4;      // queue entries per thread and marking round: their loads and atomics are in flight together
+    constexpr int UR = 2;     // keys per thread and re-insertion round
+    const int lane = tid & 63;
     const long long gc_t0 = __builtin_readcyclecounter();
     int32_t* gs = P.gs();
     const int N = S.max_nodes;
     const size_t bm_bytes = (((size_t)N + 7) / 8 + 15) & ~(size_t)15;
     uint8_t* nmark = S.gc_mark + (size_t)g * 2 * bm_bytes;
     uint8_t* omark = nmark + bm_bytes;
+    uint32_t* nmw = reinterpret_cast<uint32_t*>(nmark);
+    uint32_t* omw = reinterpret_cast<uint32_t*>(omark);
     int32_t* queue = S.gc_queue + (size_t)g * N;
     const uint32_t mask = (uint32_t)S.table_cap - 1u;
-    int phase = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_PHASE]);
+    // progress (written by thread 0 at the end of the previous slice, in an earlier launch)
+    int phase = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_PHASE]) & 15;
     int cursor = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_CURSOR]);
     int tail = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_TAIL]);
     int nfree = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_NFREE]);
     int onfree = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_ONFREE]);
-    // the slice is over when its cycle budget is spent (uniform: s_memtime is a scalar read)
-    auto over = [&]() { return budget >= 0 && (long long)__builtin_readcyclecounter() - gc_t0 > budget; };
+    // the slice is over when the deadline has passed: thread 0 looks at the clock, everybody follows
+    auto over = [&]() {
+        if (deadline < 0) return false;
+        return G_::bcast((long long)__builtin_readcyclecounter() > deadline ? 1 : 0, tid, sm) != 0;
+    };
     auto suspend = [&](int ph, int cur) {
-        __threadfence_block();
-        if (lane == 0) {
+        G_::sync();
+        if (tid == 0) {
             gs[TM_GS_GC_PHASE] = ph; gs[TM_GS_GC_CURSOR] = cur; gs[TM_GS_GC_TAIL] = tail;
             gs[TM_GS_GC_NFREE] = nfree; gs[TM_GS_GC_ONFREE] = onfree;
             gs[TM_GS_GC_CYC16] += (int)(((long long)__builtin_readcyclecounter() - gc_t0) >> 4);
             gs[TM_GS_GC_SLICES] += 1;
         }
-        __threadfence_block();
         return false;
     };
-    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
-    if (phase == 1) {
-        for (size_t i = lane; i < 2 * bm_bytes / 4; i += 64) reinterpret_cast<uint32_t*>(nmark)[i] = 0;
-        __threadfence_block();
+    if (phase == GC_REQ) {
+        for (size_t i = tid; i < 2 * bm_bytes / 4; i += T) nmw[i] = 0;      // both bitmaps
+        G_::sync();
         // breadth-first marking; index 0 is followed like any other child (core.h:41-45), so it stays occupied
-        if (lane == 0) { queue[0] = gs[TM_GS_ROOT]; bit_test_set(nmark, (uint32_t)queue[0]); }
-        __threadfence_block();
-        phase = 2; cursor = 0; tail = 1;
+        if (tid == 0) { queue[0] = gs[TM_GS_ROOT]; bit_test_set(nmark, (uint32_t)queue[0]); }
+        G_::sync();
+        phase = GC_MARK; cursor = 0; tail = 1;
     }
-    if (phase == 2) {
+    if (phase == GC_MARK) {
         int head = cursor;
         while (head < tail) {
-            int i = head + lane;
-            uint32_t ch[7] = {0, 0, 0, 0, 0, 0, 0};
-            uint32_t fresh = 0;     // bit a: child a was not marked before this round
-            if (i < tail) {
-                const int node = queue[i];
-                // all loads of the round first, then all seven test-and-set atomics back to back (their latencies overlap),
-                // then the results: a round costs one atomic round trip instead of seven
+            const int stop = min(tail, head + T * U);
+            uint32_t ch[U][7];
+            uint32_t ob[U];
+            bool val[U];
+            // all loads of the round, then all test-and-set atomics (their latencies overlap), then the results
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = head + u * T + tid;
+                val[u] = i < stop;
+                const int node = val[u] ? queue[i] : 0;
                 const uint4 k0 = *reinterpret_cast<const uint4*>(P.kids() + (size_t)node * TM_KIDS_DW);
                 const uint4 k1 = *reinterpret_cast<const uint4*>(P.kids() + (size_t)node * TM_KIDS_DW + 4);
-                const uint32_t ob = P.rec()[(size_t)node * TM_REC_DW + TM_REC_OBS];
-                ch[0] = k0.x; ch[1] = k0.y; ch[2] = k0.z; ch[3] = k0.w; ch[4] = k1.x; ch[5] = k1.y; ch[6] = k1.z;
+                ob[u] = P.rec()[(size_t)node * TM_REC_DW + TM_REC_OBS];
+                ch[u][0] = k0.x; ch[u][1] = k0.y; ch[u][2] = k0.z; ch[u][3] = k0.w; ch[u][4] = k1.x; ch[u][5] = k1.y; ch[u][6] = k1.z;
+            }
+            uint32_t fresh[U];      // bit a: child a was not marked before this round
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                // several actions of a node often lead to the same child (moves against a wall): one atomic per distinct child
+                uint32_t skip = val[u] ? 0u : 0x7Fu;
+#pragma unroll
+                for (int a = 1; a < 7; ++a)
+#pragma unroll
+                    for (int b = 0; b < a; ++b)
+                        if (ch[u][a] == ch[u][b]) skip |= 1u << a;
                 uint32_t old[7];
 #pragma unroll
                 for (int a = 0; a < 7; ++a)
-                    old[a] = atomicOr(reinterpret_cast<uint32_t*>(nmark) + (ch[a] >> 5), 1u << (ch[a] & 31));
-                atomicOr(reinterpret_cast<uint32_t*>(omark) + (ob >> 5), 1u << (ob & 31));
+                    old[a] = ((skip >> a) & 1u) ? 0xFFFFFFFFu : atomicOr(nmw + (ch[u][a] >> 5), 1u << (ch[u][a] & 31));
+                if (val[u]) atomicOr(omw + (ob[u] >> 5), 1u << (ob[u] & 31));
+                uint32_t f = 0;
 #pragma unroll
                 for (int a = 0; a < 7; ++a)
-                    if (!((old[a] >> (ch[a] & 31)) & 1u)) fresh |= 1u << a;
+                    if (!((old[a] >> (ch[u][a] & 31)) & 1u)) f |= 1u << a;
+                fresh[u] = f;
             }
-            const int cnt = __popc(fresh);
-            head = min(tail, head + 64);
-            // append this round's discoveries: exclusive scan of cnt over the wave
-            int incl = cnt;
-            for (int d = 1; d < 64; d <<= 1) {
-                int t = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += t;
-            }
-            int total = __shfl(incl, 63, 64);
-            int off = tail + incl - cnt;
+            int cnt = 0;
 #pragma unroll
-            for (int a = 0; a < 7; ++a)
-                if ((fresh >> a) & 1u) queue[off + __popc(fresh & ((1u << a) - 1u))] = (int)ch[a];
+            for (int u = 0; u < U; ++u) cnt += __popc(fresh[u]);
+            int total;
+            int off = tail + G_::exscan(cnt, tid, sm, total);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int a = 0; a < 7; ++a)
+                    if ((fresh[u] >> a) & 1u) queue[off++] = (int)ch[u][a];
+            head = stop;
             tail += total;
-            // the queue is produced and consumed by this wave only: a workgroup-scope fence (wait for the stores, same-CU
-            // L1 is write-through) is enough, the device-scope one (L2 write-back + L1 invalidate) cost microseconds per batch
-            __threadfence_block();
-            if (head < tail && over()) return suspend(2, head);
+            G_::sync();        // the queue is produced and consumed by this group only (same CU)
+            if (head < tail && over()) return suspend(GC_MARK, head);
         }
         // the root of an unexpanded tree still reaches node 0 through its zero child row
-        phase = 3; cursor = 0;
+        phase = GC_CLEAR; cursor = 0;
     }
-    if (phase == 3) {
+    if (phase == GC_CLEAR) {
         // both tables are rebuilt from what is kept: clear them first (nothing below reads them).  16-byte stores: two
         // 8-byte entries each (table_cap is a power of two, the per-game tables are 16-byte aligned)
         uint4* nt4 = reinterpret_cast<uint4*>(P.ntab());
@@ -1168,74 +1251,59 @@ __device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, in
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         const int n4 = S.table_cap / 2;
         while (cursor < n4) {
-            const int stop = min(n4, cursor + 64 * 64);     // 64 passes (128 KiB) between two looks at the clock
-            for (int i = cursor + lane; i < stop; i += 64) { nt4[i] = z4; ot4[i] = z4; }
+            const int stop = min(n4, cursor + T * 32);      // 16 KiB of each table per thread-group pass between two looks at the clock
+            for (int i = cursor + tid; i < stop; i += T) { nt4[i] = z4; ot4[i] = z4; }
             cursor = stop;
-            if (cursor < n4 && over()) return suspend(3, cursor);
+            if (cursor < n4 && over()) return suspend(GC_CLEAR, cursor);
         }
-        __threadfence_block();
-        phase = 4; cursor = 0; nfree = 0; onfree = 0;
+        G_::sync();
+        phase = GC_SWEEP; cursor = 0; nfree = 0; onfree = 0;
     }
-    // Sweeps over the pool: each lane takes one 32-bit word of a bitmap = 32 consecutive indices per pass (2048 per
-    // wave pass), so a 100 000-entry pool is 49 passes instead of 1563 dependent ones.  Free lists come out ascending
-    // (agents/agent.py:211-212,221-222): lane-major order is index order, positions from a wave prefix sum.  Freed
-    // records are cleared by store-only streams (reset_arrays, agent.py:227-244); indices below the lowest index ever
-    // allocated were never written and are skipped.
-    if (phase == 4) {
+    // Sweep over the pool: each thread takes one 32-bit word of a bitmap = 32 consecutive indices per pass.  Free lists
+    // come out ascending (agents/agent.py:211-212,221-222): thread order is index order, positions from a group prefix sum.
+    // Freed node records are not cleared here: new_node initialises a slot completely when it hands it out (the reference
+    // zeroes at GC, agents/agent.py:227-244; nothing reads a free slot in between).
+    if (phase == GC_SWEEP) {
         const int n_words = (N + 31) / 32;
-        const uint32_t* nw = reinterpret_cast<const uint32_t*>(nmark);
-        const uint32_t* ow = reinterpret_cast<const uint32_t*>(omark);
         const int low_obs = gs[TM_GS_LOW_OBS];
         const bool harvest = S.online && S.replay_cap > 0;
         int m = harvest ? S.replay_count[g] : 0;
-        int dropped = 0;
-        auto wave_scan = [&](int v, int& total) {   // inclusive prefix sum over the wave
-            int incl = v;
-            for (int d = 1; d < 64; d <<= 1) {
-                int t = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += t;
-            }
-            total = __shfl(incl, 63, 64);
-            return incl;
-        };
-        for (int wbase = cursor; wbase < n_words; wbase += 64) {
-            const int wi = wbase + lane;
+        for (int wbase = cursor; wbase < n_words; wbase += T) {
+            const int wi = wbase + tid;
             uint32_t valid = 0;
-            if (wi < n_words) { int rem = N - wi * 32; valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u); }
+            if (wi < n_words) { const int rem = N - wi * 32; valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u); }
             // ---- nodes ----
-            const uint32_t fr = (wi < n_words) ? (~nw[wi] & valid) : 0u;
+            const uint32_t fr = (wi < n_words) ? (~nmw[wi] & valid) : 0u;
             int total;
-            int pos = nfree + wave_scan(__popc(fr), total) - __popc(fr);
-            // Freed records are not cleared here: new_node initialises a slot completely when it hands it out (the
-            // reference zeroes at GC, agents/agent.py:227-244; nothing reads a free slot in between).
+            int pos = nfree + G_::exscan(__popc(fr), tid, sm, total);
             for (uint32_t bits = fr; bits; bits &= bits - 1) P.fnode()[pos++] = wi * 32 + (__ffs(bits) - 1);
             nfree += total;
             // ---- observations ----
-            const uint32_t ofr = (wi < n_words) ? (~ow[wi] & valid) : 0u;
+            const uint32_t ofr = (wi < n_words) ? (~omw[wi] & valid) : 0u;
             int ototal;
-            int opos = onfree + wave_scan(__popc(ofr), ototal) - __popc(ofr);
-            uint32_t keepmask = 0;
+            int opos = onfree + G_::exscan(__popc(ofr), tid, sm, ototal);
             if (harvest) {
                 // store_nodes (ValueSim.py:122-159): freed observations with enough visits that are not terminal
+                uint32_t keepmask = 0;
                 for (uint32_t bits = ofr; bits;) {
-                    int ob[4];
+                    int obx[4];
                     uint4 st4[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        ob[u] = bits ? (__ffs(bits) - 1) : -1;
+                        obx[u] = bits ? (__ffs(bits) - 1) : -1;
                         bits &= bits ? bits - 1 : 0u;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int o = wi * 32 + (ob[u] < 0 ? 0 : ob[u]);
-                        st4[u] = (ob[u] >= 0 && o >= low_obs) ? *reinterpret_cast<const uint4*>(P.stat() + (size_t)o * 4) : make_uint4(0, 0, 0, 0);
+                        const int o = wi * 32 + (obx[u] < 0 ? 0 : obx[u]);
+                        st4[u] = (obx[u] >= 0 && o >= low_obs) ? *reinterpret_cast<const uint4*>(P.stat() + (size_t)o * 4) : make_uint4(0, 0, 0, 0);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (ob[u] >= 0 && (int)st4[u].x >= S.min_visits_to_store && !(st4[u].x >> 31)) keepmask |= 1u << ob[u];
+                        if (obx[u] >= 0 && (int)st4[u].x >= S.min_visits_to_store && !(st4[u].x >> 31)) keepmask |= 1u << obx[u];
                 }
                 int ktotal;
-                int kpos = m + wave_scan(__popc(keepmask), ktotal) - __popc(keepmask);
+                int kpos = m + G_::exscan(__popc(keepmask), tid, sm, ktotal);
                 for (uint32_t bits = keepmask; bits; bits &= bits - 1) {
                     const int o = wi * 32 + (__ffs(bits) - 1);
                     if (kpos < S.replay_cap) {
@@ -1248,25 +1316,18 @@ __device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, in
                     }
                     kpos += 1;
                 }
-                if (m + ktotal > S.replay_cap) dropped += m + ktotal - S.replay_cap;   // never silently (the reference keeps all up to memory_size)
+                // never silently (the reference keeps all up to memory_size)
+                if (tid == 0 && m + ktotal > S.replay_cap) gs[TM_GS_N_DROPPED] += m + ktotal - S.replay_cap;
                 m = min(S.replay_cap, m + ktotal);
             }
-            for (uint32_t bits = (wi < n_words) ? (ow[wi] & valid) : 0u; bits; bits &= bits - 1) {
-                const int o = wi * 32 + (__ffs(bits) - 1);     // kept observation: back into the (cleared) table
-                if (o == 0) continue;
-                uint32_t key[OBS_DW];
-                const uint4* src = reinterpret_cast<const uint4*>(P.okey() + (size_t)o * OBS_DW);
-                for (int t = 0; t < 3; ++t) { uint4 v = src[t]; key[4*t] = v.x; key[4*t+1] = v.y; key[4*t+2] = v.z; key[4*t+3] = v.w; }
-                const uint64_t h = hash_obs(key);
-                uint32_t sl = (uint32_t)h & mask;
-                const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)o;
-                while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.otab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
-            }
             // Of a freed observation only the statistics are cleared (16 B): a visit count of 0 is what keeps a slot that
-            // stays free from being harvested again at the next GC.  Fully free words: one contiguous 512-byte store.
+            // stays free from being harvested again at the next GC.  Fully free words: one contiguous 512-byte store by
+            // the word's wave.  (The harvest above has read its statistics: a wave's loads are complete before its stores
+            // are issued only through the data dependence - hence the explicit group barrier.)
+            if (harvest) G_::sync();
             const bool ofull = (wi < n_words) && valid == 0xFFFFFFFFu && ofr == 0xFFFFFFFFu && (wi * 32 >= low_obs);
             for (uint64_t fm = __ballot(ofull); fm; fm &= fm - 1) {
-                const int w0 = (wbase + (__ffsll((long long)fm) - 1)) * 32;
+                const int w0 = (wbase + (tid & ~63) + (__ffsll((long long)fm) - 1)) * 32;
                 if (lane < 32) reinterpret_cast<uint4*>(P.stat() + (size_t)w0 * 4)[lane] = make_uint4(0, 0, 0, 0);
             }
             for (uint32_t bits = ofr; bits; bits &= bits - 1) {
@@ -1275,49 +1336,120 @@ __device__ __forceinline__ bool gc_run(const tm_store& S, const GP& P, int g, in
                 if (o >= low_obs && !ofull) *reinterpret_cast<uint4*>(P.stat() + (size_t)o * 4) = make_uint4(0, 0, 0, 0);
             }
             onfree += ototal;
-            if (harvest && lane == 0) { S.replay_count[g] = m; if (dropped) { gs[TM_GS_N_DROPPED] += dropped; } }
-            dropped = 0;
-            if (wbase + 64 < n_words && over()) return suspend(4, wbase + 64);
+            if (harvest) { G_::sync(); if (tid == 0) S.replay_count[g] = m; }
+            if (wbase + T < n_words && over()) return suspend(GC_SWEEP, wbase + T);
         }
-        __threadfence_block();
-        phase = 5; cursor = 0;
+        G_::sync();
+        phase = GC_NODES; cursor = 0;
     }
-    if (phase == 5) {
-        // re-insert the kept nodes (the BFS queue lists them): lanes claim empty slots with a 64-bit compare-and-swap (no
+    if (phase == GC_NODES) {
+        // re-insert the kept nodes (the queue lists them): threads claim empty slots with a 64-bit compare-and-swap (no
         // deletions happen concurrently, so linear probing stays consistent; placement order does not affect lookups)
-        for (int base = cursor; base < tail; base += 64) {
-            int q = base + lane;
-            int i = (q < tail) ? queue[q] : 0;
-            if (i != 0) {
-                uint32_t key[GAME_DW];
-                const uint4* src = reinterpret_cast<const uint4*>(P.game() + (size_t)i * GAME_DW);
-                for (int t = 0; t < 4; ++t) { uint4 v = src[t]; key[4*t] = v.x; key[4*t+1] = v.y; key[4*t+2] = v.z; key[4*t+3] = v.w; }
-                uint64_t h = hash_game(key);
+        for (int base = cursor; base < tail; base += T * UR) {
+            uint4 key[UR][4];
+            int idx[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int q = base + u * T + tid;
+                idx[u] = (q < tail) ? queue[q] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const uint4* src = reinterpret_cast<const uint4*>(P.game() + (size_t)idx[u] * GAME_DW);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) key[u][t] = src[t];
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                if (idx[u] == 0) continue;
+                uint32_t kw[GAME_DW];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { kw[4*t] = key[u][t].x; kw[4*t+1] = key[u][t].y; kw[4*t+2] = key[u][t].z; kw[4*t+3] = key[u][t].w; }
+                const uint64_t h = hash_game(kw);
                 uint32_t sl = (uint32_t)h & mask;
-                unsigned long long ent = ((h >> 32) << 32) | (uint32_t)i;
+                const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)idx[u];
                 while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.ntab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
             }
-            if (base + 64 < tail && over()) return suspend(5, base + 64);
+            if (base + T * UR < tail && over()) return suspend(GC_NODES, base + T * UR);
+        }
+        phase = GC_OBS; cursor = 0;
+    }
+    if (phase == GC_OBS) {
+        // the kept observations, by index (the bitmap says which), back into their (cleared) table
+        for (int base = cursor; base < N; base += T * UR) {
+            uint4 key[UR][3];
+            bool kept[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int o = base + u * T + tid;
+                kept[u] = o > 0 && o < N && bit_test(omark, (uint32_t)o);
+                const uint4* src = reinterpret_cast<const uint4*>(P.okey() + (size_t)(kept[u] ? o : 0) * OBS_DW);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) key[u][t] = src[t];
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                if (!kept[u]) continue;
+                const int o = base + u * T + tid;
+                uint32_t kw[OBS_DW];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { kw[4*t] = key[u][t].x; kw[4*t+1] = key[u][t].y; kw[4*t+2] = key[u][t].z; kw[4*t+3] = key[u][t].w; }
+                const uint64_t h = hash_obs(kw);
+                uint32_t sl = (uint32_t)h & mask;
+                const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)o;
+                while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.otab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
+            }
+            if (base + T * UR < N && over()) return suspend(GC_OBS, base + T * UR);
         }
     }
-    if (lane == 0) {
+    G_::sync();
+    if (tid == 0) {
         gs[TM_GS_NFREE_NODE] = nfree;
         gs[TM_GS_NFREE_OBS] = onfree;
         gs[TM_GS_N_GC] += 1;
         gs[TM_GS_CYC_TAIL] = gs[TM_GS_GC_CYC16] + (int)(((long long)__builtin_readcyclecounter() - gc_t0) >> 4);   // last GC, units of 16 cycles
         gs[TM_GS_CYC_TAIL + 1] = tail;                                                // reachable nodes at the last GC
-        gs[TM_GS_GC_PHASE] = 0; gs[TM_GS_GC_CURSOR] = 0; gs[TM_GS_GC_CYC16] = 0;
+        gs[TM_GS_GC_PHASE] = done_word; gs[TM_GS_GC_CURSOR] = 0; gs[TM_GS_GC_CYC16] = 0;
         gs[TM_GS_GC_SLICES] += 1;
     }
-    __threadfence_block();   // same-wave ordering only (the game is private to this wave); the device-scope fence writes the L2 back
+    G_::sync();
     return true;
 }
-// to completion, now (update_root's exhausting pop: once per move at most, and almost never)
-__device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, WaveLds& L, int g, int lane) {
-    (void)L;
-    if (lane == 0) P.gs()[TM_GS_GC_PHASE] = 1;
+// to completion, now, by the game's own wave (update_root's exhausting pop: once per move at most, and almost never; the
+// single-call entry points)
+__device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, int lane) {
+    if (lane == 0) P.gs()[TM_GS_GC_PHASE] = GC_REQ;
     __threadfence_block();
-    gc_run(S, P, g, lane, -1);
+    gc_collect<64>(S, P, g, lane, -1, nullptr, 0);
+}
+
+// A collector workgroup of a k_sim_step launch: the games [first, last) of its range whose collection was requested in
+// an earlier launch (or is in progress), one after the other, until the deadline.
+__device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags, int n_gc, int* sm /* >= 8 + 256 ints of LDS */) {
+    constexpr int T = 64 * WPB;
+    const int tid = threadIdx.x;
+    const int seq = (int)((unsigned)flags >> 8);
+    const int per = (S.n_games + n_gc - 1) / n_gc;
+    const int first = blockIdx.x * per, last = min(S.n_games, first + per);
+    const long long budget = ((flags & TM_SIM_GC_FULL) || S.gc_slice_cycles <= 0) ? -1 : (long long)S.gc_slice_cycles;
+    const long long deadline = budget < 0 ? -1 : (long long)__builtin_readcyclecounter() + budget;
+    int* list = sm + 8;
+    for (int base = first; base < last; base += T) {
+        const int g = base + tid;
+        const int word = g < last ? S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_PHASE] : 0;
+        const int ph = word & 15;
+        const bool todo = (ph >= GC_MARK && ph <= GC_OBS) || (ph == GC_REQ && (word >> 4) != seq);
+        int total;
+        const int pos = Grp<T>::exscan(todo ? 1 : 0, tid, sm, total);
+        if (todo) list[pos] = g;
+        __syncthreads();
+        for (int k = 0; k < total; ++k) {
+            const int gk = list[k];
+            if (!gc_collect<T>(S, game_ptrs(S, gk), gk, tid, deadline, sm, (seq << 4) | GC_DONE)) return;   // out of time
+            if (deadline >= 0 && Grp<T>::bcast((long long)__builtin_readcyclecounter() > deadline ? 1 : 0, tid, sm)) return;
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1329,21 +1461,32 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     extern __shared__ __attribute__((aligned(16))) MtLds mt_lds[];   // WPB entries, only in the VANILLA instantiation
     // the wave index is uniform by construction: say so, and every per-game base pointer lives in scalar registers
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int g = blockIdx.x * WPB + w;
+    // The first workgroups of the grid are collectors: each looks after the garbage collections of a range of games, in
+    // slices of S.gc_slice_cycles per launch (catch-up launches pass TM_SIM_GC_FULL: to completion), beside the
+    // simulation workgroups - they are dispatched first and share the CUs with them (a k_sim_step wave needs 70 registers).
+    const int n_gc = gc_blocks(S.n_games);
+    if ((int)blockIdx.x < n_gc) {
+        static_assert(sizeof(WaveLds) * WPB >= (8 + 64 * WPB) * sizeof(int), "collector scratch");
+        gc_collector_block(S, flags, n_gc, reinterpret_cast<int*>(lds));
+        return;
+    }
+    const int g = ((int)blockIdx.x - n_gc) * WPB + w;
     if (g >= S.n_games) return;
     GP P = game_ptrs(S, g);
     WaveLds& L = lds[w];
     int32_t* gs = P.gs();
     // The game's control block (64 words) in one coalesced load: word i in lane i, read with v_readlane.  A word is read
-    // from the snapshot only before this launch writes it (the halves below write each word once, from lane 0); the
-    // snapshot is taken again after a collection, which rewrites the free-list words.
-    int gsv = gs[lane];
-    if (GSV(gsv, TM_GS_GC_PHASE) != 0) {
-        // this game is collecting garbage: one slice per launch (S.gc_slice_cycles; 0 = to completion), no simulation
-        // (catch-up launches pass TM_SIM_GC_FULL: only laggards are left, nobody is held up by a collection run to its end)
-        const bool sliced = S.gc_slice_cycles > 0 && !(flags & TM_SIM_GC_FULL);
-        if (!gc_run(S, P, g, lane, sliced ? (long long)S.gc_slice_cycles : -1)) return;
-        gsv = gs[lane];
+    // from the snapshot only before this launch writes it (the halves below write each word once, from lane 0).
+    const int gsv = gs[lane];
+    const int gc_req_word = (int)(((unsigned)flags >> 8) << 4) | GC_REQ;
+    {
+        // a collection requested, in progress, or completed in THIS launch: the game does not simulate (what a collector
+        // workgroup of this launch writes is not ordered with this wave's reads); completed in an earlier launch: resume
+        const int gcw = GSV(gsv, TM_GS_GC_PHASE);
+        if (gcw != 0) {
+            if ((gcw & 15) != GC_DONE || (gcw >> 4) == (int)((unsigned)flags >> 8)) return;
+            if (lane == 0) gs[TM_GS_GC_PHASE] = 0;
+        }
     }
     const int pend = GSV(gsv, TM_GS_PENDING);
     if (pend == 2) {
@@ -1351,7 +1494,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         const int leaf = GSV(gsv, TM_GS_LEAF);
         const uint32_t self_o = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_OBS];
         const uint32_t self_sc = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_SCORE];
-        wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc, gsv);
+        wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc, gsv, gc_req_word);
         return;
     }
     const long long t0 = __builtin_readcyclecounter();
@@ -1363,7 +1506,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     if (lane == 0) gs[TM_GS_CYC_BACK] = (int)(t1 - t0);
     // the per-move quota (tm_move_begin): games that lost launches to a collection catch up in extra launches
     if ((flags & TM_SIM_FRONT) && GSV(gsv, TM_GS_SIM_STARTED) < GSV(gsv, TM_GS_SIM_TARGET))
-        wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane, gsv);
+        wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane, gsv, gc_req_word);
     else if (lane < S.eval_slots) P.eval_obs()[lane] = 0;   // nothing started: no request (the evaluator skips empty slots)
 }
 
@@ -1381,7 +1524,7 @@ __global__ void k_sims_remaining(tm_store S, int32_t* out) {
     int r = 0;
     if (g < S.n_games) {
         const int32_t* gs = S.gs + (size_t)g * TM_GS_DW;
-        r = (gs[TM_GS_SIM_TARGET] - gs[TM_GS_SIM_STARTED]) + (gs[TM_GS_PENDING] != 0 ? 1 : 0) + (gs[TM_GS_GC_PHASE] != 0 ? 1 : 0);
+        r = (gs[TM_GS_SIM_TARGET] - gs[TM_GS_SIM_STARTED]) + (gs[TM_GS_PENDING] != 0 ? 1 : 0) + (gs[TM_GS_GC_PHASE] != 0 && (gs[TM_GS_GC_PHASE] & 15) != GC_DONE ? 1 : 0);
     }
     for (int d = 32; d >= 1; d >>= 1) r = max(r, __shfl_xor(r, d, 64));
     if ((threadIdx.x & 63) == 0 && r > 0) atomicMax(out, r);
@@ -1400,7 +1543,7 @@ __global__ __launch_bounds__(64 * WPB) void k_update_root(tm_store S) {
     int idx, o;
     wave_new_nodes(S, P, L, g, 1, lane, idx, o);
     if (idx < 0) {
-        gc_wave(S, P, L, g, lane);   // reachable set of the OLD root, as in the reference
+        gc_wave(S, P, g, lane);   // reachable set of the OLD root, as in the reference
         wave_new_nodes(S, P, L, g, 1, lane, idx, o);
         if (idx < 0) { if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_POOL); idx = 0; }
     }
@@ -1429,7 +1572,7 @@ __global__ __launch_bounds__(64 * WPB) void k_tree_node(tm_store S, const uint32
     int idx, o;
     wave_new_nodes(S, P, L, g, 1, lane, idx, o);
     if (idx < 0) {
-        gc_wave(S, P, L, g, lane);
+        gc_wave(S, P, g, lane);
         wave_new_nodes(S, P, L, g, 1, lane, idx, o);
         if (idx < 0) { if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_POOL); idx = 0; }
     }
@@ -1441,23 +1584,23 @@ __global__ __launch_bounds__(64 * WPB) void k_tree_node(tm_store S, const uint32
         const uint32_t self_sc = P.rec()[(size_t)idx * TM_REC_DW + TM_REC_SCORE];
         const int gsv = P.gs()[lane];
         uint32_t lh;
-        if (wave_expand(S, P, L, g, lane, idx, self_sc, lh, gsv)) break;
+        if (wave_expand(S, P, L, g, lane, idx, self_sc, lh, gsv, GC_REQ)) break;
         // the pool ran dry at one of the seven pops: the collection wave_expand asked for, now, then the expansion again
         // (the successors already inserted are transposition hits; a second failure is TM_ERR_POOL inside wave_expand)
         __threadfence_block();
-        gc_run(S, P, g, lane, -1);
+        gc_collect<64>(S, P, g, lane, -1, nullptr, 0);
     }
     if (lane == 0) { P.gs()[TM_GS_GC_RETRY] = 0; P.gs()[TM_GS_N_EXPAND] += 1; }
 }
-// TreeAgent.remove_nodes() (agent.cpp:337-..., agents/agent.py:246-257) as a call of its own
+// TreeAgent.remove_nodes() (agent.cpp:337-..., agents/agent.py:246-257) as a call of its own: one workgroup per game
 __global__ __launch_bounds__(64 * WPB) void k_tree_gc(tm_store S, const uint8_t* __restrict__ mask) {
-    __shared__ WaveLds lds[WPB];
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int g = blockIdx.x * WPB + w;
-    if (g >= S.n_games) return;
+    __shared__ int sm[16];
+    const int g = blockIdx.x;
     if (mask && !mask[g]) return;
     GP P = game_ptrs(S, g);
-    gc_wave(S, P, lds[w], g, lane);
+    if (threadIdx.x == 0) P.gs()[TM_GS_GC_PHASE] = GC_REQ;
+    __syncthreads();
+    gc_collect<64 * WPB>(S, P, g, (int)threadIdx.x, -1, sm, 0);
 }
 
 // compute_stats + get_action (agents/agent.py:153-185; agent.cpp:149-172 for the all-C++ kinds)
@@ -1705,11 +1848,15 @@ int tm_tree_expand(const tm_store* s, const uint32_t* games, const uint8_t* mask
     return TM_LAUNCH_CHECK();
 }
 int tm_tree_remove_nodes(const tm_store* s, const uint8_t* mask, void* stream) {
-    hipLaunchKernelGGL(k_tree_gc, dim3((s->n_games + WPB - 1) / WPB), dim3(64 * WPB), 0, (hipStream_t)stream, *s, mask);
+    hipLaunchKernelGGL(k_tree_gc, dim3(s->n_games), dim3(64 * WPB), 0, (hipStream_t)stream, *s, mask);
     return TM_LAUNCH_CHECK();
 }
 int tm_sim_step(const tm_store* s, int flags, void* stream) {
-    const dim3 grid((s->n_games + WPB - 1) / WPB), block(64 * WPB);
+    // the launch number (bits 8.. of the kernel's flags): what orders a game's wave and its collector workgroup, which
+    // only ever hand over at kernel boundaries.  Any two launches that touch the same game differ in it.
+    static std::atomic<unsigned> launch_seq{0};
+    flags = (flags & 0xFF) | (int)(((launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
+    const dim3 grid((s->n_games + WPB - 1) / WPB + gc_blocks(s->n_games)), block(64 * WPB);
     if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
         hipLaunchKernelGGL(k_sim_step<true>, grid, block, WPB * sizeof(MtLds), (hipStream_t)stream, *s, flags);
     else
