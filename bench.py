@@ -220,7 +220,7 @@ def main():
                       "scripts/selfplay_online.py -> profiles/*_online_learning.jsonl" % (args.warmup + 1, args.warmup + args.steps),
         "error_games": int(err),
         "walk_mispredicted_levels": S.counter("N_WALK_MISS") / max(S.counter("TRACE_SUM"), 1),
-        "gc": {"collections": int(n_gc), "slices": int(gc_slices), "catchup_launches": int(catchup),
+        "gc": {"collections": int(n_gc), "slices": int(gc_slices), "catchup_launches": int(catchup), "collector_only_launches": int(ss.get("gc_launches", 0)),
                "dropped_tuples": int(dropped), "trees_restarted_pool_outgrown": int(pool_resets)},
         "store_gib_per_gpu": S.nbytes() / 2**30,
         "last_sim_phase_kcycles": {k: float(S.t["gs"][:, st.GS[k]].float().mean().item()) / 1e3

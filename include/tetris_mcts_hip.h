@@ -33,6 +33,7 @@ extern "C" {
 #define TM_KIDS_DW 8       /* raw children row: child[7] in action order + pad */
 #define TM_GS_DW 64        /* per-game control block */
 #define TM_LEAF_DW 32      /* per-game leaf hand-off between the front and back halves of a simulation */
+#define TM_GC_PART_DW 128   /* per-game scratch of a collection: (free nodes, free observations, harvested tuples) per collector workgroup */
 #define TM_VALUENET_PARAMS 478342
 #define TM_VALUENET_SCRATCH 9728       /* floats of scratch per state, tm_valuenet_forward_plain */
 #define TM_VALUENET_SCRATCH_MFMA 2048  /* floats of scratch per state, tm_valuenet_forward */
@@ -53,11 +54,15 @@ enum {
     TM_GS_LOW_NODE = 26, TM_GS_LOW_OBS,  /* lowest node / observation index ever allocated (GC skips untouched entries) */
     TM_GS_FIRST_MISS = 28, /* levels of the last walk that were taken over from the walk before it (verified in parallel, tree.hip) */
     TM_GS_PREFIX_SUM,      /* sum of TM_GS_FIRST_MISS over all simulations */
-    /* resumable garbage collection (a game that collects does not simulate in that launch) */
-    TM_GS_GC_PHASE = 32, /* 0 none, 1 requested, 2 marking, 3 clearing the tables, 4 sweeping, 5 re-inserting */
-    TM_GS_GC_CURSOR, TM_GS_GC_TAIL, TM_GS_GC_NFREE, TM_GS_GC_ONFREE,
-    TM_GS_GC_CYC16,      /* cycles/16 spent so far in the collection in progress */
-    TM_GS_GC_SLICES,     /* launches that ran a slice of a collection (all collections) */
+    /* garbage collection by the collector workgroups of tm_sim_step (a game that collects does not simulate; tree.hip) */
+    TM_GS_GC_PHASE = 32, /* 0 none; (launch << 4) | 1 requested; 2 marking, 3 counting, 4 writing the free lists, 5 re-inserting;
+                            (launch << 4) | 7 complete (the game resumes in a later launch) */
+    TM_GS_GC_ARRIVE,     /* collector workgroups that have done their share of the current step (bits 8..: some left work) */
+    TM_GS_GC_TAIL,       /* nodes discovered so far (queue length; device-scope atomic) */
+    TM_GS_GC_TAIL0,      /* the same as of the start of the launch */
+    TM_GS_GC_HEAD0,      /* every queue entry below this one has been processed */
+    TM_GS_GC_MINLEFT,    /* lowest queue position a collector workgroup left unprocessed in this launch (device-scope atomic min) */
+    TM_GS_GC_SLICES,     /* launches in which collector workgroups worked on a collection of this game (all collections) */
     TM_GS_GC_RETRY,      /* the suspended expansion has already been through a collection */
     /* per-move simulation quota: tm_move_begin adds `sims` to the target; a launch starts a simulation for a game only
        while started < target, so games that lost launches to a collection catch up in extra launches (tm_sims_remaining) */
@@ -96,7 +101,7 @@ typedef struct tm_store {
     int32_t min_visits_to_store; /* ValueSim.py:14 / ValueSimLP.py:11 */
     int32_t online;       /* harvest replay tuples on GC (ValueSim.py:109-115) */
     int32_t replay_cap;   /* capacity (tuples) of the replay buffer */
-    int32_t gc_slice_cycles; /* shader cycles a collecting game spends per launch before it yields (0: collect to completion) */
+    int32_t gc_slice_cycles; /* shader cycles the collector workgroups of a tm_sim_step launch may spend marking (0: no limit) */
     double gamma;
     /* node store, per game contiguous */
     uint32_t *node_rec;   /* [G][N][32] 7 x (child, obs, score, own score) unique children in selection order, then (0, self_obs, self_score, hdr) */
@@ -126,6 +131,7 @@ typedef struct tm_store {
     int32_t *replay_count;/* [G] */
     uint32_t *mt_state;   /* [G][625] CPython random state per game (624 words + index), TM_KIND_VANILLA / TM_KIND_VANILLA_C rollouts (Vanilla.py:4,52) */
     uint32_t *node_child; /* [G][N][8] raw child[7] per action (agents/agent.py:61) + pad */
+    int32_t *gc_part;     /* [G][TM_GC_PART_DW] per-collector counts of a collection in progress */
 } tm_store;
 
 /* pools, free lists, tables, rng (seed 1), control blocks.  Everything else must be zero-filled by the caller. */
@@ -160,7 +166,10 @@ int tm_tree_remove_nodes(const tm_store *s, const uint8_t *mask, void *stream); 
  * quota left, backs up its pending one, or - when the game's node pool ran dry - runs one slice of its garbage
  * collection instead (s->gc_slice_cycles), so `sims` launches + 1 are enough unless a game collected in this move. */
 int tm_move_begin(const tm_store *s, int sims, void *stream);
-int tm_sims_remaining(const tm_store *s, int32_t *out /* device int: max over games of launches still needed */, void *stream);
+int tm_sims_remaining(const tm_store *s, int32_t *out /* device int[2]: max over games of launches still needed; games whose collection is under way */, void *stream);
+/* one step of every garbage collection under way (the collector workgroups of tm_sim_step alone, no simulation): what the
+ * driver launches instead of whole simulation launches while it waits for collections at the end of a move */
+int tm_gc_step(const tm_store *s, void *stream);
 #define TM_SIM_BACKUP 1  /* finish the pending simulation: backup with eval_v/eval_var */
 #define TM_SIM_FRONT 2   /* start one: select, expand, post evaluation requests into eval_obs */
 #define TM_SIM_GC_FULL 4 /* a game that is collecting garbage finishes the collection in this launch (catch-up launches) */

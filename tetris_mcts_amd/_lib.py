@@ -21,7 +21,7 @@ class TmStore(C.Structure):
         ("node_rec", vp), ("node_game", vp), ("obs_stat", vp), ("obs_key", vp), ("node_tab", vp), ("obs_tab", vp),
         ("free_node", vp), ("free_obs", vp), ("gs", vp), ("rng", vp), ("env_game", vp), ("env_line_stats", vp),
         ("trace", vp), ("leaf", vp), ("eval_obs", vp), ("eval_v", vp), ("eval_var", vp), ("nq_table", vp),
-        ("gc_mark", vp), ("gc_queue", vp), ("replay_obs", vp), ("replay_stat", vp), ("replay_count", vp), ("mt_state", vp), ("node_child", vp),
+        ("gc_mark", vp), ("gc_queue", vp), ("replay_obs", vp), ("replay_stat", vp), ("replay_count", vp), ("mt_state", vp), ("node_child", vp), ("gc_part", vp),
     ]
 
 
@@ -41,6 +41,7 @@ SYMBOLS = {
     "tm_sim_step": [C.POINTER(TmStore), i32, vp],
     "tm_move_begin": [C.POINTER(TmStore), i32, vp],
     "tm_sims_remaining": [C.POINTER(TmStore), vp, vp],
+    "tm_gc_step": [C.POINTER(TmStore), vp],
     "tm_eval_render": [C.POINTER(TmStore), vp, vp],
     "tm_root_stats": [C.POINTER(TmStore), vp, vp, vp],
     "tm_export_game": [C.POINTER(TmStore), i32, vp, vp, vp, vp, vp, vp, vp, vp],

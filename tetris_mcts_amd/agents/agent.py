@@ -95,12 +95,16 @@ class TreeAgent(Agent):
         both = st.SIM_BACKUP | st.SIM_FRONT
         s.move_begin(sims)
         s.sim_step(both)
-        todo, flags = sims, both
+        todo = sims
         while todo > 0:
             for _ in range(todo):
                 self.evaluate_requests()
-                s.sim_step(flags)
-            todo, flags = s.sims_remaining(), both | st.SIM_GC_FULL      # catch-up: collections in progress run to their end
+                s.sim_step(both)
+            todo, collecting = s.sims_remaining()
+            while collecting:                      # catch-up: collections under way are finished by collector-only launches
+                for _ in range(6):
+                    s.gc_step()
+                todo, collecting = s.sims_remaining()
 
     def play(self):
         self.mcts(self.sims)

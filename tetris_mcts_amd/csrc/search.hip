@@ -35,7 +35,7 @@ struct tm_search {
     std::vector<hipEvent_t> ev;      // triples: before value net, after value net (= before tree), after tree
     int ev_used;
     double tree_ms, nn_ms;
-    long long n_timed, n_runs, extra_launches, launches;
+    long long n_timed, n_runs, extra_launches, launches, gc_launches;
 };
 
 #define TM_TRY(x) do { int e_ = (int)(x); if (e_ != 0) return e_; } while (0)
@@ -68,6 +68,7 @@ int tm_store_slice(const tm_store* s, int first, int n, tm_store* out) {
     t.eval_var += f * (size_t)s->eval_slots;
     t.gc_mark += f * 2 * bm_bytes;
     t.gc_queue += f * N;
+    t.gc_part += f * TM_GC_PART_DW;
     if (t.replay_obs) t.replay_obs += f * (size_t)s->replay_cap * TM_OBS_DW;
     if (t.replay_stat) t.replay_stat += f * (size_t)s->replay_cap * 4;
     if (t.replay_count) t.replay_count += f;
@@ -85,7 +86,7 @@ int tm_search_create(tm_search** out, const tm_store* s, int n_sub, int ev_every
     h->ev_every = ev_every;
     h->ev_used = 0;
     h->tree_ms = h->nn_ms = 0;
-    h->n_timed = h->n_runs = h->extra_launches = h->launches = 0;
+    h->n_timed = h->n_runs = h->extra_launches = h->launches = h->gc_launches = 0;
     // sub-batch boundaries on multiples of 4 games (one workgroup of the tree kernel = 4 games)
     const int G = s->n_games;
     int per = ((G + n_sub - 1) / n_sub + 3) & ~3;
@@ -113,9 +114,9 @@ int tm_search_create(tm_search** out, const tm_store* s, int n_sub, int ev_every
         if (e != hipSuccess) return (int)e;
         h->ev_done.push_back(d);
     }
-    e = hipMalloc(&h->rem_dev, sizeof(int32_t) * n_sub);
+    e = hipMalloc(&h->rem_dev, sizeof(int32_t) * 2 * n_sub);
     if (e != hipSuccess) return (int)e;
-    e = hipHostMalloc(&h->rem_host, sizeof(int32_t) * n_sub, hipHostMallocDefault);
+    e = hipHostMalloc(&h->rem_host, sizeof(int32_t) * 2 * n_sub, hipHostMallocDefault);
     if (e != hipSuccess) return (int)e;
     *out = h;
     return 0;
@@ -177,23 +178,30 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
             if (e3) TM_TRY(hipEventRecord(e3[2], st[k]));
         }
     }
-    // catch-up: games that spent launches collecting garbage still owe simulations
+    // catch-up: games that spent launches collecting garbage still owe simulations.  Collections still under way are
+    // finished first, by collector-only launches (tm_gc_step: a step of every collection each, no simulation, no evaluator).
     for (;;) {
         for (int k = 0; k < K; ++k) {
-            h->rem_host[k] = 0;
+            h->rem_host[2 * k] = h->rem_host[2 * k + 1] = 0;
             if (h->sub[k].n_games == 0) continue;
-            TM_TRY(tm_sims_remaining(&h->sub[k], h->rem_dev + k, st[k]));
-            TM_TRY(hipMemcpyAsync(h->rem_host + k, h->rem_dev + k, sizeof(int32_t), hipMemcpyDeviceToHost, st[k]));
+            TM_TRY(tm_sims_remaining(&h->sub[k], h->rem_dev + 2 * k, st[k]));
+            TM_TRY(hipMemcpyAsync(h->rem_host + 2 * k, h->rem_dev + 2 * k, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st[k]));
         }
         for (int k = 0; k < K; ++k) TM_TRY(hipStreamSynchronize(st[k]));
-        int r = 0;
-        for (int k = 0; k < K; ++k) r = h->rem_host[k] > r ? h->rem_host[k] : r;
+        int r = 0, collecting = 0;
+        for (int k = 0; k < K; ++k) { r = h->rem_host[2 * k] > r ? h->rem_host[2 * k] : r; collecting += h->rem_host[2 * k + 1]; }
         if (r == 0) break;
+        if (collecting > 0) {
+            for (int i = 0; i < 6; ++i)
+                for (int k = 0; k < K; ++k)
+                    if (h->rem_host[2 * k + 1] > 0) { TM_TRY(tm_gc_step(&h->sub[k], st[k])); h->gc_launches += 1; }
+            continue;
+        }
         for (int i = 0; i < r; ++i)
             for (int k = 0; k < K; ++k)
-                if (h->rem_host[k] > i) {
+                if (h->rem_host[2 * k] > i) {
                     TM_TRY(nn(k));
-                    TM_TRY(step(k, TM_SIM_GC_FULL));      // only laggards are left: a collection in progress runs to its end
+                    TM_TRY(step(k));
                     h->extra_launches += 1;
                 }
     }
@@ -210,14 +218,14 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
     return 0;
 }
 
-// out[0..6] = runs, tree-kernel launches, catch-up launches, timed samples, sum of tree-kernel ms, sum of value-net ms,
-// sub-batches; the sums are over the timed samples (sub-batch 0, every ev_every-th simulation)
+// out[0..7] = runs, tree-kernel launches, catch-up launches, timed samples, sum of tree-kernel ms, sum of value-net ms,
+// sub-batches, collector-only launches; the sums are over the timed samples (sub-batch 0, every ev_every-th simulation)
 int tm_search_stats(tm_search* h, double* out, int n, int reset) {
-    double v[7] = {(double)h->n_runs, (double)h->launches, (double)h->extra_launches, (double)h->n_timed, h->tree_ms,
-                   h->nn_ms, (double)h->n_sub};
-    for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
-    if (reset) { h->tree_ms = h->nn_ms = 0; h->n_timed = h->n_runs = h->extra_launches = h->launches = 0; }
-    return 7;
+    double v[8] = {(double)h->n_runs, (double)h->launches, (double)h->extra_launches, (double)h->n_timed, h->tree_ms,
+                   h->nn_ms, (double)h->n_sub, (double)h->gc_launches};
+    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+    if (reset) { h->tree_ms = h->nn_ms = 0; h->n_timed = h->n_runs = h->extra_launches = h->launches = h->gc_launches = 0; }
+    return 8;
 }
 
 }  // extern "C"

@@ -1089,8 +1089,8 @@ __device__ __forceinline__ bool bit_test(const uint8_t* bm, uint32_t i) {
 // carries the launch number for that: a request is (launch << 4) | 1 and is picked up by the collectors of LATER
 // launches; a finished collection leaves (launch << 4) | 7 and the game's wave resumes in a LATER launch.
 // ---------------------------------------------------------------------------------------------------
-constexpr int GC_REQ = 1, GC_MARK = 2, GC_CLEAR = 3, GC_SWEEP = 4, GC_NODES = 5, GC_OBS = 6, GC_DONE = 7;
-constexpr int GC_BLOCKS_MAX = 32;   // collector workgroups of a k_sim_step launch (each serves a contiguous range of games)
+constexpr int GC_REQ = 1, GC_DONE = 7;   // phase word: (launch << 4) | GC_REQ requested, 2..5 under way (GCP_*), (launch << 4) | GC_DONE complete
+constexpr int GC_BLOCKS_MAX = 64;   // collector workgroups of a k_sim_step launch: the first half does the bounded steps, the second half the marking
 __host__ __device__ inline int gc_blocks(int n_games) {
     const int sim_blocks = (n_games + WPB - 1) / WPB;
     return sim_blocks < GC_BLOCKS_MAX ? sim_blocks : GC_BLOCKS_MAX;
@@ -1139,10 +1139,10 @@ template <int T> struct Grp {
     }
 };
 
-// Returns true when the collection is complete.  deadline < 0: no deadline.  done_word: what the phase word becomes at the
-// end (0, or (launch << 4) | GC_DONE for a collector workgroup).  sm: Grp<T>::NW + 1 ints of LDS (unused for T == 64).
+// One group of T threads, the whole collection, now (update_root's exhausting pop, the single-call entry points,
+// tm_tree_remove_nodes).  sm: Grp<T>::NW + 1 ints of LDS (unused for T == 64).
 template <int T>
-__device__ __forceinline__ bool gc_collect(const tm_store& S, const GP& P, int g, int tid, long long deadline, int* sm, int done_word) {
+__device__ __forceinline__ void gc_collect(const tm_store& S, const GP& P, int g, int tid, int* sm) {
     typedef Grp<T> G_;
     constexpr int U = 4;      // queue entries per thread and marking round: their loads and atomics are in flight together
     constexpr int UR = 2;     // keys per thread and re-insertion round
@@ -1157,37 +1157,16 @@ __device__ __forceinline__ bool gc_collect(const tm_store& S, const GP& P, int g
     uint32_t* omw = reinterpret_cast<uint32_t*>(omark);
     int32_t* queue = S.gc_queue + (size_t)g * N;
     const uint32_t mask = (uint32_t)S.table_cap - 1u;
-    // progress (written by thread 0 at the end of the previous slice, in an earlier launch)
-    int phase = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_PHASE]) & 15;
-    int cursor = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_CURSOR]);
-    int tail = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_TAIL]);
-    int nfree = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_NFREE]);
-    int onfree = __builtin_amdgcn_readfirstlane(gs[TM_GS_GC_ONFREE]);
-    // the slice is over when the deadline has passed: thread 0 looks at the clock, everybody follows
-    auto over = [&]() {
-        if (deadline < 0) return false;
-        return G_::bcast((long long)__builtin_readcyclecounter() > deadline ? 1 : 0, tid, sm) != 0;
-    };
-    auto suspend = [&](int ph, int cur) {
-        G_::sync();
-        if (tid == 0) {
-            gs[TM_GS_GC_PHASE] = ph; gs[TM_GS_GC_CURSOR] = cur; gs[TM_GS_GC_TAIL] = tail;
-            gs[TM_GS_GC_NFREE] = nfree; gs[TM_GS_GC_ONFREE] = onfree;
-            gs[TM_GS_GC_CYC16] += (int)(((long long)__builtin_readcyclecounter() - gc_t0) >> 4);
-            gs[TM_GS_GC_SLICES] += 1;
-        }
-        return false;
-    };
-    if (phase == GC_REQ) {
+    int tail = 1, nfree = 0, onfree = 0;
+    {
         for (size_t i = tid; i < 2 * bm_bytes / 4; i += T) nmw[i] = 0;      // both bitmaps
         G_::sync();
         // breadth-first marking; index 0 is followed like any other child (core.h:41-45), so it stays occupied
         if (tid == 0) { queue[0] = gs[TM_GS_ROOT]; bit_test_set(nmark, (uint32_t)queue[0]); }
         G_::sync();
-        phase = GC_MARK; cursor = 0; tail = 1;
     }
-    if (phase == GC_MARK) {
-        int head = cursor;
+    {
+        int head = 0;
         while (head < tail) {
             const int stop = min(tail, head + T * U);
             uint32_t ch[U][7];
@@ -1238,37 +1217,29 @@ __device__ __forceinline__ bool gc_collect(const tm_store& S, const GP& P, int g
             head = stop;
             tail += total;
             G_::sync();        // the queue is produced and consumed by this group only (same CU)
-            if (head < tail && over()) return suspend(GC_MARK, head);
         }
         // the root of an unexpanded tree still reaches node 0 through its zero child row
-        phase = GC_CLEAR; cursor = 0;
     }
-    if (phase == GC_CLEAR) {
+    {
         // both tables are rebuilt from what is kept: clear them first (nothing below reads them).  16-byte stores: two
         // 8-byte entries each (table_cap is a power of two, the per-game tables are 16-byte aligned)
         uint4* nt4 = reinterpret_cast<uint4*>(P.ntab());
         uint4* ot4 = reinterpret_cast<uint4*>(P.otab());
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         const int n4 = S.table_cap / 2;
-        while (cursor < n4) {
-            const int stop = min(n4, cursor + T * 32);      // 16 KiB of each table per thread-group pass between two looks at the clock
-            for (int i = cursor + tid; i < stop; i += T) { nt4[i] = z4; ot4[i] = z4; }
-            cursor = stop;
-            if (cursor < n4 && over()) return suspend(GC_CLEAR, cursor);
-        }
+        for (int i = tid; i < n4; i += T) { nt4[i] = z4; ot4[i] = z4; }
         G_::sync();
-        phase = GC_SWEEP; cursor = 0; nfree = 0; onfree = 0;
     }
     // Sweep over the pool: each thread takes one 32-bit word of a bitmap = 32 consecutive indices per pass.  Free lists
     // come out ascending (agents/agent.py:211-212,221-222): thread order is index order, positions from a group prefix sum.
     // Freed node records are not cleared here: new_node initialises a slot completely when it hands it out (the reference
     // zeroes at GC, agents/agent.py:227-244; nothing reads a free slot in between).
-    if (phase == GC_SWEEP) {
+    {
         const int n_words = (N + 31) / 32;
         const int low_obs = gs[TM_GS_LOW_OBS];
         const bool harvest = S.online && S.replay_cap > 0;
         int m = harvest ? S.replay_count[g] : 0;
-        for (int wbase = cursor; wbase < n_words; wbase += T) {
+        for (int wbase = 0; wbase < n_words; wbase += T) {
             const int wi = wbase + tid;
             uint32_t valid = 0;
             if (wi < n_words) { const int rem = N - wi * 32; valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u); }
@@ -1337,15 +1308,13 @@ __device__ __forceinline__ bool gc_collect(const tm_store& S, const GP& P, int g
             }
             onfree += ototal;
             if (harvest) { G_::sync(); if (tid == 0) S.replay_count[g] = m; }
-            if (wbase + T < n_words && over()) return suspend(GC_SWEEP, wbase + T);
         }
         G_::sync();
-        phase = GC_NODES; cursor = 0;
     }
-    if (phase == GC_NODES) {
+    {
         // re-insert the kept nodes (the queue lists them): threads claim empty slots with a 64-bit compare-and-swap (no
         // deletions happen concurrently, so linear probing stays consistent; placement order does not affect lookups)
-        for (int base = cursor; base < tail; base += T * UR) {
+        for (int base = 0; base < tail; base += T * UR) {
             uint4 key[UR][4];
             int idx[UR];
 #pragma unroll
@@ -1370,13 +1339,11 @@ __device__ __forceinline__ bool gc_collect(const tm_store& S, const GP& P, int g
                 const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)idx[u];
                 while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.ntab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
             }
-            if (base + T * UR < tail && over()) return suspend(GC_NODES, base + T * UR);
         }
-        phase = GC_OBS; cursor = 0;
     }
-    if (phase == GC_OBS) {
+    {
         // the kept observations, by index (the bitmap says which), back into their (cleared) table
-        for (int base = cursor; base < N; base += T * UR) {
+        for (int base = 0; base < N; base += T * UR) {
             uint4 key[UR][3];
             bool kept[UR];
 #pragma unroll
@@ -1399,7 +1366,6 @@ __device__ __forceinline__ bool gc_collect(const tm_store& S, const GP& P, int g
                 const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)o;
                 while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.otab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
             }
-            if (base + T * UR < N && over()) return suspend(GC_OBS, base + T * UR);
         }
     }
     G_::sync();
@@ -1407,46 +1373,445 @@ __device__ __forceinline__ bool gc_collect(const tm_store& S, const GP& P, int g
         gs[TM_GS_NFREE_NODE] = nfree;
         gs[TM_GS_NFREE_OBS] = onfree;
         gs[TM_GS_N_GC] += 1;
-        gs[TM_GS_CYC_TAIL] = gs[TM_GS_GC_CYC16] + (int)(((long long)__builtin_readcyclecounter() - gc_t0) >> 4);   // last GC, units of 16 cycles
+        gs[TM_GS_CYC_TAIL] = (int)(((long long)__builtin_readcyclecounter() - gc_t0) >> 4);   // last GC, units of 16 cycles
         gs[TM_GS_CYC_TAIL + 1] = tail;                                                // reachable nodes at the last GC
-        gs[TM_GS_GC_PHASE] = done_word; gs[TM_GS_GC_CURSOR] = 0; gs[TM_GS_GC_CYC16] = 0;
+        gs[TM_GS_GC_PHASE] = 0;
         gs[TM_GS_GC_SLICES] += 1;
     }
     G_::sync();
-    return true;
 }
 // to completion, now, by the game's own wave (update_root's exhausting pop: once per move at most, and almost never; the
 // single-call entry points)
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, int lane) {
     if (lane == 0) P.gs()[TM_GS_GC_PHASE] = GC_REQ;
     __threadfence_block();
-    gc_collect<64>(S, P, g, lane, -1, nullptr, 0);
+    gc_collect<64>(S, P, g, lane, nullptr);
 }
 
-// A collector workgroup of a k_sim_step launch: the games [first, last) of its range whose collection was requested in
-// an earlier launch (or is in progress), one after the other, until the deadline.
-__device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags, int n_gc, int* sm /* >= 8 + 256 ints of LDS */) {
+// ---------------------------------------------------------------------------------------------------
+// The same collection as the work of ALL collector workgroups of a k_sim_step launch (one CU can not sweep a
+// 100 000-entry pool quickly: a round trip costs over a microsecond beside 4096 walking waves).  Every collecting game
+// goes through five steps, one launch each except the marking; in each, collector workgroup c of n does share c of the
+// work, then ARRIVES (one device-scope atomic per game and workgroup); the last to arrive moves the game to the next
+// step.  The kernel boundary is the barrier between steps: nothing a workgroup writes is read by another in the same
+// launch, except through those atomics and the mark bitmaps (device-scope atomics as well).
+//   1 init    the bitmaps and the root by workgroup g % n, the two tables cleared by all
+//   2 mark    the queue holds every node discovered so far (bit 31 of an entry: its children have been marked); each
+//             workgroup takes its share of the entries that are not processed yet, marks their children (atomicOr: one
+//             workgroup sees a child first), appends what it discovers to the queue (atomic reservation) and goes on
+//             with its own discoveries until the launch's deadline; what it leaves is found by the next launch's scan.
+//             Complete when no workgroup left anything.
+//   3 count   free nodes / free observations / harvested tuples per share of the index range
+//   4 write   ascending free lists (agents/agent.py:211-212,221-222), replay tuples in index order, freed statistics
+//             cleared - at the offsets the counts give
+//   5, 6      kept nodes, then kept observations, back into their tables (compare-and-swap)
+// All workgroups see the same games in the same steps: the control blocks they read were written in earlier launches.
+// A collection in progress must be continued by launches over the same range of games (same n).
+// ---------------------------------------------------------------------------------------------------
+constexpr int GCP_INIT = GC_REQ, GCP_MARK = 2, GCP_COUNT = 3, GCP_WRITE = 4, GCP_NODES = 5, GCP_OBS = 6;
+constexpr int GC_LIST_MAX = 64;      // collecting games looked after per launch (the others wait)
+constexpr int GC_COST_MAX = 6;       // per launch: cost units of the steps whose shares are done without looking at the clock
+                                     // (init 1, count 1, write 2, nodes 5, observations 5: about 5 microseconds a unit)
+constexpr int GC_RING = 32;          // chunks of own discoveries a workgroup remembers while marking
+struct GcLds {
+    int scan[8];                     // Grp<256> scratch
+    int n_list;
+    int list_g[GC_LIST_MAX], list_ph[GC_LIST_MAX];
+    int ring_start[GC_RING], ring_cnt[GC_RING];
+};
+
+// thread 0 of a workgroup, after the workgroup's stores for this game: returns true for the last workgroup to arrive
+__device__ __forceinline__ bool gc_arrive(int32_t* gs, int n_gc, bool leftover, bool& any_left) {
+    const int add = 1 + (leftover ? 256 : 0);
+    const int old = atomicAdd(&gs[TM_GS_GC_ARRIVE], add);
+    if ((old & 255) != n_gc - 1) return false;
+    any_left = ((old + add) >> 8) != 0;
+    atomicExch(&gs[TM_GS_GC_ARRIVE], 0);
+    gs[TM_GS_GC_SLICES] += 1;
+    return true;
+}
+
+__device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags, int n_gc, GcLds& M) {
     constexpr int T = 64 * WPB;
-    const int tid = threadIdx.x;
+    typedef Grp<T> G_;
+    const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.x;
     const int seq = (int)((unsigned)flags >> 8);
-    const int per = (S.n_games + n_gc - 1) / n_gc;
-    const int first = blockIdx.x * per, last = min(S.n_games, first + per);
     const long long budget = ((flags & TM_SIM_GC_FULL) || S.gc_slice_cycles <= 0) ? -1 : (long long)S.gc_slice_cycles;
     const long long deadline = budget < 0 ? -1 : (long long)__builtin_readcyclecounter() + budget;
-    int* list = sm + 8;
-    for (int base = first; base < last; base += T) {
-        const int g = base + tid;
-        const int word = g < last ? S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_PHASE] : 0;
-        const int ph = word & 15;
-        const bool todo = (ph >= GC_MARK && ph <= GC_OBS) || (ph == GC_REQ && (word >> 4) != seq);
-        int total;
-        const int pos = Grp<T>::exscan(todo ? 1 : 0, tid, sm, total);
-        if (todo) list[pos] = g;
+    int* sm = M.scan;
+    auto over = [&]() {
+        if (deadline < 0) return false;
+        return G_::bcast((long long)__builtin_readcyclecounter() > deadline ? 1 : 0, tid, sm) != 0;
+    };
+    // ---- which games are collecting (requested in an earlier launch, or under way), in game order ----
+    // thread t looks at a contiguous run of games (all its loads in flight together, one prefix sum for the whole list)
+    int n_list = 0;
+    {
+        constexpr int RUN = 16;
+        for (int base = 0; base < S.n_games && n_list < GC_LIST_MAX; base += T * RUN) {
+            int word[RUN];
+#pragma unroll
+            for (int r = 0; r < RUN; ++r) {
+                const int g = base + tid * RUN + r;
+                word[r] = g < S.n_games ? S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_PHASE] : 0;
+            }
+            uint32_t todo = 0;
+#pragma unroll
+            for (int r = 0; r < RUN; ++r) {
+                const int ph = word[r] & 15;
+                if ((ph >= GCP_MARK && ph <= GCP_OBS) || (ph == GC_REQ && (word[r] >> 4) != seq)) todo |= 1u << r;
+            }
+            int total;
+            int pos = n_list + G_::exscan(__popc(todo), tid, sm, total);
+            for (uint32_t bits = todo; bits; bits &= bits - 1) {
+                const int r = __ffs(bits) - 1;
+                if (pos < GC_LIST_MAX) { M.list_g[pos] = base + tid * RUN + r; M.list_ph[pos] = word[r] & 15; }
+                pos += 1;
+            }
+            n_list = min(GC_LIST_MAX, n_list + total);
+        }
+    }
+    __syncthreads();
+    if (n_list == 0) return;
+    const int N = S.max_nodes;
+    const size_t bm_bytes = (((size_t)N + 7) / 8 + 15) & ~(size_t)15;
+    const uint32_t mask = (uint32_t)S.table_cap - 1u;
+    const int n_words = (N + 31) / 32;
+    const bool harvest = S.online && S.replay_cap > 0;
+    // First pass: the bounded steps, as many as fit the launch's cost allowance, starting at a game that rotates with the
+    // launch number (nobody waits behind the low indices for ever) - every workgroup picks the same ones.
+    // Second pass: the marking.  It is a breadth-first walk whose depth, not its size, sets its duration (a round trip per
+    // level, a hundred levels and more), so the games that are marking do not share the time but the WORKGROUPS: game j of
+    // the n_mark marking games is looked after by the workgroups c with c % n_mark == j (all of them arrive for every game).
+    int n_mark = 0;
+    for (int k = 0; k < n_list; ++k) n_mark += M.list_ph[k] == GCP_MARK ? 1 : 0;
+    int cost_left = deadline < 0 ? 1 << 20 : GC_COST_MAX, mark_j = 0;      // (collector-only launches: nothing to hold up)
+    for (int kk = 0; kk < 2 * n_list; ++kk) {
+        const int k = (kk + seq) % n_list;
+        const int g = M.list_g[k], ph = M.list_ph[k];
+        if ((kk < n_list) == (ph == GCP_MARK)) continue;
+        long long my_deadline = deadline;
+        // this workgroup's share of the step's work: part my_part of n_parts (-1: none, it only arrives).  Workgroups
+        // [0, n_b) do the bounded steps, [n_b, n_gc) the marking (a lone workgroup does both): a launch's bounded work must
+        // not take the marking's time, nor the other way round.
+        const int n_b = n_gc >= 2 ? n_gc / 2 : 1, n_m = n_gc >= 2 ? n_gc - n_b : 1;
+        int my_part, n_parts;
+        if (ph != GCP_MARK) {
+            const int cost = ph == GCP_WRITE ? 2 : (ph == GCP_NODES || ph == GCP_OBS) ? 5 : 1;
+            if (cost > cost_left) continue;               // every workgroup skips the same games
+            cost_left -= cost;
+            n_parts = n_b;
+            my_part = c < n_b ? c : -1;
+        } else {
+            const int j = mark_j++;
+            const int cm = n_gc >= 2 ? c - n_b : 0;       // index among the marking workgroups (< 0: not one of them)
+            if (n_mark <= n_m) {
+                n_parts = n_m / n_mark + (j < n_m % n_mark ? 1 : 0);
+                my_part = (cm >= 0 && cm % n_mark == j) ? cm / n_mark : -1;
+            } else {
+                // more games marking than workgroups: workgroup j % n_m takes the whole of game j, its time shared
+                n_parts = 1;
+                my_part = (cm >= 0 && j % n_m == cm) ? 0 : -1;
+                if (my_part == 0 && deadline >= 0) {
+                    const long long t0_ = (long long)__builtin_readcyclecounter();     // thread 0's clock for everybody
+                    const long long t = ((long long)G_::bcast((int)(t0_ >> 32), tid, sm) << 32) | (unsigned)G_::bcast((int)t0_, tid, sm);
+                    const int mine_left = (n_mark - 1 - j) / n_m + 1;
+                    my_deadline = t >= deadline ? deadline : t + (deadline - t) / mine_left;
+                }
+            }
+        }
+        const long long p0 = my_part < 0 ? 0 : my_part, p1 = my_part < 0 ? 0 : my_part + 1;      // share = [x * p0 / n_parts, x * p1 / n_parts)
+        const GP P = game_ptrs(S, g);
+        int32_t* gs = P.gs();
+        uint32_t* nmw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes);
+        uint32_t* omw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes + bm_bytes);
+        int32_t* queue = S.gc_queue + (size_t)g * N;
+        int32_t* part = S.gc_part + (size_t)g * TM_GC_PART_DW;
+        bool leftover = false;
+        if (ph == GCP_INIT) {
+            uint4* nt4 = reinterpret_cast<uint4*>(P.ntab());
+            uint4* ot4 = reinterpret_cast<uint4*>(P.otab());
+            const uint4 z4 = make_uint4(0, 0, 0, 0);
+            const long long n4 = S.table_cap / 2;
+            const int lo = (int)(n4 * p0 / n_parts), hi = (int)(n4 * p1 / n_parts);
+            for (int i = lo + tid; i < hi; i += T) { nt4[i] = z4; ot4[i] = z4; }
+            if (my_part == g % n_parts) {
+                for (size_t i = tid; i < 2 * bm_bytes / 4; i += T) nmw[i] = 0;      // both bitmaps
+                __syncthreads();
+                // breadth-first marking; index 0 is followed like any other child (core.h:41-45), so it stays occupied
+                if (tid == 0) { const int root = gs[TM_GS_ROOT]; queue[0] = root; nmw[root >> 5] = 1u << (root & 31); }
+            }
+        } else if (ph == GCP_MARK) {
+            constexpr int U = 4;
+            // the entries [head0, tail0) may hold unprocessed ones (everything below head0 is processed): the marking
+            // workgroups of this game share that range
+            const long long head0 = gs[TM_GS_GC_HEAD0], span0 = gs[TM_GS_GC_TAIL0] - head0;
+            int cur = (int)(head0 + span0 * p0 / n_parts), cur_end = (int)(head0 + span0 * p1 / n_parts);
+            int ring_h = 0, ring_n = 0;          // chunks of this workgroup's own discoveries still to be processed
+            int dropped_min = 0x7FFFFFFF;        // chunks that did not fit the ring: the next launch's scan finds their entries
+            auto over_my = [&]() {
+                if (my_deadline < 0) return false;
+                return G_::bcast((long long)__builtin_readcyclecounter() > my_deadline ? 1 : 0, tid, sm) != 0;
+            };
+            bool timeup = over_my();
+            while (!timeup) {
+                if (cur >= cur_end) {
+                    if (ring_n == 0) break;
+                    cur = M.ring_start[ring_h]; cur_end = cur + M.ring_cnt[ring_h];
+                    ring_h = (ring_h + 1) % GC_RING; ring_n -= 1;
+                }
+                const int stop = min(cur_end, cur + T * U);
+                uint32_t ch[U][7];
+                uint32_t ob[U];
+                bool val[U];
+                int ent[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = cur + u * T + tid;
+                    ent[u] = i < stop ? queue[i] : -1;
+                    val[u] = ent[u] >= 0;                        // bit 31: already processed
+                }
+                if (!__syncthreads_or(val[0] || val[1] || val[2] || val[3])) {      // everything here was processed in an earlier launch
+                    cur = stop;
+                    timeup = over_my();
+                    continue;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = cur + u * T + tid;
+                    const int node = val[u] ? ent[u] : 0;
+                    const uint4 k0 = *reinterpret_cast<const uint4*>(P.kids() + (size_t)node * TM_KIDS_DW);
+                    const uint4 k1 = *reinterpret_cast<const uint4*>(P.kids() + (size_t)node * TM_KIDS_DW + 4);
+                    ob[u] = P.rec()[(size_t)node * TM_REC_DW + TM_REC_OBS];
+                    ch[u][0] = k0.x; ch[u][1] = k0.y; ch[u][2] = k0.z; ch[u][3] = k0.w; ch[u][4] = k1.x; ch[u][5] = k1.y; ch[u][6] = k1.z;
+                    if (val[u]) queue[i] = ent[u] | (int)0x80000000;
+                }
+                uint32_t fresh[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    // several actions of a node often lead to the same child (moves against a wall): one atomic per distinct child
+                    uint32_t skip = val[u] ? 0u : 0x7Fu;
+#pragma unroll
+                    for (int a = 1; a < 7; ++a)
+#pragma unroll
+                        for (int b = 0; b < a; ++b)
+                            if (ch[u][a] == ch[u][b]) skip |= 1u << a;
+                    uint32_t old[7];
+#pragma unroll
+                    for (int a = 0; a < 7; ++a)
+                        old[a] = ((skip >> a) & 1u) ? 0xFFFFFFFFu : atomicOr(nmw + (ch[u][a] >> 5), 1u << (ch[u][a] & 31));
+                    if (val[u]) atomicOr(omw + (ob[u] >> 5), 1u << (ob[u] & 31));
+                    uint32_t f = 0;
+#pragma unroll
+                    for (int a = 0; a < 7; ++a)
+                        if (!((old[a] >> (ch[u][a] & 31)) & 1u)) f |= 1u << a;
+                    fresh[u] = f;
+                }
+                int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) cnt += __popc(fresh[u]);
+                int total;
+                int off = G_::exscan(cnt, tid, sm, total);
+                int qbase = 0;
+                if (total > 0) {
+                    qbase = G_::bcast(tid == 0 ? atomicAdd(&gs[TM_GS_GC_TAIL], total) : 0, tid, sm);
+                    off += qbase;
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int a = 0; a < 7; ++a)
+                            if ((fresh[u] >> a) & 1u) queue[off++] = (int)ch[u][a];
+                    if (ring_n < GC_RING) {
+                        if (tid == 0) { const int s = (ring_h + ring_n) % GC_RING; M.ring_start[s] = qbase; M.ring_cnt[s] = total; }
+                        ring_n += 1;
+                    } else dropped_min = min(dropped_min, qbase);
+                }
+                cur = stop;
+                __syncthreads();          // the queue entries and the ring are this workgroup's own (same CU)
+                timeup = over_my();
+            }
+            // what this workgroup leaves unprocessed, and the lowest queue position of it (for the next launch's scan)
+            int min_left = dropped_min;
+            if (cur < cur_end) min_left = min(min_left, cur);
+            for (int r = 0; r < ring_n; ++r) min_left = min(min_left, M.ring_start[(ring_h + r) % GC_RING]);
+            leftover = min_left != 0x7FFFFFFF;
+            if (leftover && tid == 0) atomicMin(&gs[TM_GS_GC_MINLEFT], min_left);
+        } else if (ph == GCP_COUNT) {
+            const int lo = (int)((long long)n_words * p0 / n_parts), hi = (int)((long long)n_words * p1 / n_parts);
+            const int low_obs = gs[TM_GS_LOW_OBS];
+            int nf = 0, of = 0, kf = 0;
+            for (int wi = lo + tid; wi < hi; wi += T) {
+                const int rem = N - wi * 32;
+                const uint32_t valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+                nf += __popc(~nmw[wi] & valid);
+                const uint32_t ofr = ~omw[wi] & valid;
+                of += __popc(ofr);
+                if (harvest && wi * 32 + 31 >= low_obs) {
+                    for (uint32_t bits = ofr; bits; bits &= bits - 1) {
+                        const int o = wi * 32 + (__ffs(bits) - 1);
+                        const uint32_t x = o >= low_obs ? P.stat()[(size_t)o * 4] : 0u;
+                        if ((int)x >= S.min_visits_to_store && !(x >> 31)) kf += 1;
+                    }
+                }
+            }
+            int t0, t1, t2;
+            G_::exscan(nf, tid, sm, t0);
+            G_::exscan(of, tid, sm, t1);
+            G_::exscan(kf, tid, sm, t2);
+            if (tid == 0 && my_part >= 0) { part[3 * my_part] = t0; part[3 * my_part + 1] = t1; part[3 * my_part + 2] = t2; }
+        } else if (ph == GCP_WRITE) {
+            // Freed node records are not cleared: new_node initialises a slot completely when it hands it out (the reference
+            // zeroes at GC, agents/agent.py:227-244; nothing reads a free slot in between).  Of a freed observation only
+            // the statistics are cleared (16 B): a visit count of 0 keeps a slot that stays free from being harvested again.
+            const int lo = (int)((long long)n_words * p0 / n_parts), hi = (int)((long long)n_words * p1 / n_parts);
+            const int low_obs = gs[TM_GS_LOW_OBS];
+            int nbase = 0, obase = 0, kbase = harvest ? S.replay_count[g] : 0;      // (the count is updated by the step's last workgroup)
+            for (int b = 0; b < my_part; ++b) { nbase += part[3 * b]; obase += part[3 * b + 1]; kbase += part[3 * b + 2]; }
+            for (int wbase = lo; wbase < hi; wbase += T) {
+                const int wi = wbase + tid;
+                uint32_t valid = 0;
+                if (wi < hi) { const int rem = N - wi * 32; valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u); }
+                const uint32_t fr = (wi < hi) ? (~nmw[wi] & valid) : 0u;
+                int total;
+                int pos = nbase + G_::exscan(__popc(fr), tid, sm, total);
+                for (uint32_t bits = fr; bits; bits &= bits - 1) P.fnode()[pos++] = wi * 32 + (__ffs(bits) - 1);
+                nbase += total;
+                const uint32_t ofr = (wi < hi) ? (~omw[wi] & valid) : 0u;
+                int ototal;
+                int opos = obase + G_::exscan(__popc(ofr), tid, sm, ototal);
+                obase += ototal;
+                if (harvest) {
+                    // store_nodes (ValueSim.py:122-159): freed observations with enough visits that are not terminal
+                    uint32_t keepmask = 0;
+                    if (wi < hi && wi * 32 + 31 >= low_obs)
+                        for (uint32_t bits = ofr; bits; bits &= bits - 1) {
+                            const int o = wi * 32 + (__ffs(bits) - 1);
+                            const uint32_t x = o >= low_obs ? P.stat()[(size_t)o * 4] : 0u;
+                            if ((int)x >= S.min_visits_to_store && !(x >> 31)) keepmask |= 1u << (o & 31);
+                        }
+                    int ktotal;
+                    int kpos = kbase + G_::exscan(__popc(keepmask), tid, sm, ktotal);
+                    kbase += ktotal;
+                    for (uint32_t bits = keepmask; bits; bits &= bits - 1) {
+                        const int o = wi * 32 + (__ffs(bits) - 1);
+                        if (kpos < S.replay_cap) {
+                            const uint4 st = *reinterpret_cast<const uint4*>(P.stat() + (size_t)o * 4);
+                            const uint4* sk = reinterpret_cast<const uint4*>(P.okey() + (size_t)o * TM_OBS_DW);
+                            uint4* dk = reinterpret_cast<uint4*>(S.replay_obs + ((size_t)g * S.replay_cap + kpos) * TM_OBS_DW);
+                            dk[0] = sk[0]; dk[1] = sk[1]; dk[2] = sk[2];
+                            float* ds = S.replay_stat + ((size_t)g * S.replay_cap + kpos) * 4;
+                            ds[0] = __uint_as_float(st.y); ds[1] = __uint_as_float(st.z); ds[2] = (float)(int)st.x; ds[3] = 0.f;
+                        }
+                        kpos += 1;
+                    }
+                }
+                // (a thread clears only statistics it has read itself above: program order)
+                for (uint32_t bits = ofr; bits; bits &= bits - 1) {
+                    const int o = wi * 32 + (__ffs(bits) - 1);
+                    P.fobs()[opos++] = o;
+                    if (o >= low_obs) *reinterpret_cast<uint4*>(P.stat() + (size_t)o * 4) = make_uint4(0, 0, 0, 0);
+                }
+            }
+        } else if (ph == GCP_NODES) {
+            constexpr int UR = 2;
+            const long long tail = gs[TM_GS_GC_TAIL0];
+            {
+                const int lo = (int)(tail * p0 / n_parts), hi = (int)(tail * p1 / n_parts);
+                for (int base = lo; base < hi; base += T * UR) {
+                    uint4 key[UR][4];
+                    int idx[UR];
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) {
+                        const int q = base + u * T + tid;
+                        idx[u] = (q < hi) ? (queue[q] & 0x7FFFFFFF) : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) {
+                        const uint4* src = reinterpret_cast<const uint4*>(P.game() + (size_t)idx[u] * GAME_DW);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) key[u][t] = src[t];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) {
+                        if (idx[u] == 0) continue;
+                        uint32_t kw[GAME_DW];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { kw[4*t] = key[u][t].x; kw[4*t+1] = key[u][t].y; kw[4*t+2] = key[u][t].z; kw[4*t+3] = key[u][t].w; }
+                        const uint64_t h = hash_game(kw);
+                        uint32_t sl = (uint32_t)h & mask;
+                        const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)idx[u];
+                        while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.ntab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
+                    }
+                }
+            }
+        } else {    // GCP_OBS
+            constexpr int UR = 2;
+            {
+                const int lo = (int)((long long)N * p0 / n_parts), hi = (int)((long long)N * p1 / n_parts);
+                for (int base = lo; base < hi; base += T * UR) {
+                    uint4 key[UR][3];
+                    bool kept[UR];
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) {
+                        const int o = base + u * T + tid;
+                        kept[u] = o > 0 && o < hi && ((omw[o >> 5] >> (o & 31)) & 1u);
+                        const uint4* src = reinterpret_cast<const uint4*>(P.okey() + (size_t)(kept[u] ? o : 0) * OBS_DW);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) key[u][t] = src[t];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) {
+                        if (!kept[u]) continue;
+                        const int o = base + u * T + tid;
+                        uint32_t kw[OBS_DW];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) { kw[4*t] = key[u][t].x; kw[4*t+1] = key[u][t].y; kw[4*t+2] = key[u][t].z; kw[4*t+3] = key[u][t].w; }
+                        const uint64_t h = hash_obs(kw);
+                        uint32_t sl = (uint32_t)h & mask;
+                        const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)o;
+                        while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.otab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
+                    }
+                }
+            }
+        }
+        // ---- arrive; the last workgroup moves the game on ----
         __syncthreads();
-        for (int k = 0; k < total; ++k) {
-            const int gk = list[k];
-            if (!gc_collect<T>(S, game_ptrs(S, gk), gk, tid, deadline, sm, (seq << 4) | GC_DONE)) return;   // out of time
-            if (deadline >= 0 && Grp<T>::bcast((long long)__builtin_readcyclecounter() > deadline ? 1 : 0, tid, sm)) return;
+        if (tid == 0) {
+            bool any_left = false;
+            if (gc_arrive(gs, n_gc, leftover, any_left)) {
+                if (ph == GCP_INIT) {
+                    atomicExch(&gs[TM_GS_GC_TAIL], 1);
+                    atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF);
+                    gs[TM_GS_GC_TAIL0] = 1;
+                    gs[TM_GS_GC_HEAD0] = 0;
+                    gs[TM_GS_GC_PHASE] = GCP_MARK;
+                } else if (ph == GCP_MARK) {
+                    const int tl = atomicAdd(&gs[TM_GS_GC_TAIL], 0);
+                    gs[TM_GS_GC_TAIL0] = tl;
+                    gs[TM_GS_GC_HEAD0] = min(tl, atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF));
+                    if (!any_left) gs[TM_GS_GC_PHASE] = GCP_COUNT;
+                } else if (ph == GCP_COUNT) {
+                    gs[TM_GS_GC_PHASE] = GCP_WRITE;
+                } else if (ph == GCP_WRITE) {
+                    // the totals, from the counts of the launch before (nothing is exchanged inside a launch)
+                    int nf = 0, of = 0, kf = 0;
+                    for (int b = 0; b < n_b; ++b) { nf += part[3 * b]; of += part[3 * b + 1]; kf += part[3 * b + 2]; }
+                    gs[TM_GS_NFREE_NODE] = nf;
+                    gs[TM_GS_NFREE_OBS] = of;
+                    if (harvest) {
+                        const int m0 = S.replay_count[g];
+                        if (m0 + kf > S.replay_cap) gs[TM_GS_N_DROPPED] += m0 + kf - S.replay_cap;   // never silently (the reference keeps all up to memory_size)
+                        S.replay_count[g] = min(S.replay_cap, m0 + kf);
+                    }
+                    gs[TM_GS_GC_PHASE] = GCP_NODES;
+                } else if (ph == GCP_NODES) {
+                    gs[TM_GS_GC_PHASE] = GCP_OBS;
+                } else {
+                    gs[TM_GS_N_GC] += 1;
+                    gs[TM_GS_CYC_TAIL + 1] = gs[TM_GS_GC_TAIL0];      // reachable nodes at the last GC
+                    gs[TM_GS_GC_PHASE] = (seq << 4) | GC_DONE;
+                }
+            }
         }
         __syncthreads();
     }
@@ -1466,8 +1831,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     // simulation workgroups - they are dispatched first and share the CUs with them (a k_sim_step wave needs 70 registers).
     const int n_gc = gc_blocks(S.n_games);
     if ((int)blockIdx.x < n_gc) {
-        static_assert(sizeof(WaveLds) * WPB >= (8 + 64 * WPB) * sizeof(int), "collector scratch");
-        gc_collector_block(S, flags, n_gc, reinterpret_cast<int*>(lds));
+        static_assert(sizeof(WaveLds) * WPB >= sizeof(GcLds), "collector scratch");
+        gc_collector_block(S, flags, n_gc, *reinterpret_cast<GcLds*>(lds));
         return;
     }
     const int g = ((int)blockIdx.x - n_gc) * WPB + w;
@@ -1521,13 +1886,15 @@ __global__ void k_move_begin(tm_store S, int sims) {
 // + one launch for the pending backup + one if a collection is in progress); atomicMax into *out (zeroed by the caller)
 __global__ void k_sims_remaining(tm_store S, int32_t* out) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    int r = 0;
+    int r = 0, col = 0;
     if (g < S.n_games) {
         const int32_t* gs = S.gs + (size_t)g * TM_GS_DW;
-        r = (gs[TM_GS_SIM_TARGET] - gs[TM_GS_SIM_STARTED]) + (gs[TM_GS_PENDING] != 0 ? 1 : 0) + (gs[TM_GS_GC_PHASE] != 0 && (gs[TM_GS_GC_PHASE] & 15) != GC_DONE ? 1 : 0);
+        const int ph = gs[TM_GS_GC_PHASE] & 15;
+        col = (ph != 0 && ph != GC_DONE) ? 1 : 0;
+        r = (gs[TM_GS_SIM_TARGET] - gs[TM_GS_SIM_STARTED]) + (gs[TM_GS_PENDING] != 0 ? 1 : 0) + col;
     }
-    for (int d = 32; d >= 1; d >>= 1) r = max(r, __shfl_xor(r, d, 64));
-    if ((threadIdx.x & 63) == 0 && r > 0) atomicMax(out, r);
+    for (int d = 32; d >= 1; d >>= 1) { r = max(r, __shfl_xor(r, d, 64)); col += __shfl_xor(col, d, 64); }
+    if ((threadIdx.x & 63) == 0) { if (r > 0) atomicMax(out, r); if (col > 0) atomicAdd(out + 1, col); }
 }
 
 // agent.update_root(game) (agents/agent.py:296-301)
@@ -1588,7 +1955,7 @@ __global__ __launch_bounds__(64 * WPB) void k_tree_node(tm_store S, const uint32
         // the pool ran dry at one of the seven pops: the collection wave_expand asked for, now, then the expansion again
         // (the successors already inserted are transposition hits; a second failure is TM_ERR_POOL inside wave_expand)
         __threadfence_block();
-        gc_collect<64>(S, P, g, lane, -1, nullptr, 0);
+        gc_collect<64>(S, P, g, lane, nullptr);
     }
     if (lane == 0) { P.gs()[TM_GS_GC_RETRY] = 0; P.gs()[TM_GS_N_EXPAND] += 1; }
 }
@@ -1600,7 +1967,7 @@ __global__ __launch_bounds__(64 * WPB) void k_tree_gc(tm_store S, const uint8_t*
     GP P = game_ptrs(S, g);
     if (threadIdx.x == 0) P.gs()[TM_GS_GC_PHASE] = GC_REQ;
     __syncthreads();
-    gc_collect<64 * WPB>(S, P, g, (int)threadIdx.x, -1, sm, 0);
+    gc_collect<64 * WPB>(S, P, g, (int)threadIdx.x, sm);
 }
 
 // compute_stats + get_action (agents/agent.py:153-185; agent.cpp:149-172 for the all-C++ kinds)
@@ -1684,7 +2051,7 @@ __global__ void k_pool_reset(tm_store S, const uint8_t* mask) {
         P.gs()[TM_GS_GC_PHASE] = 0;
         P.gs()[TM_GS_GC_RETRY] = 0;
         P.gs()[TM_GS_POOL_FULL] = 0;
-        P.gs()[TM_GS_GC_CYC16] = 0;
+        P.gs()[TM_GS_GC_ARRIVE] = 0;
         P.gs()[TM_GS_SIM_STARTED] = P.gs()[TM_GS_SIM_TARGET];
         P.gs()[TM_GS_ERR] &= ~TM_ERR_POOL;
         P.gs()[TM_GS_N_POOL_RESET] += 1;
@@ -1789,6 +2156,7 @@ __global__ void k_export_game(tm_store S, int g, int32_t* child, float* score, i
 // ---------------------------------------------------------------------------------------------------
 using namespace tmcts;
 #define TM_LAUNCH_CHECK() ((int)hipGetLastError())
+static std::atomic<unsigned> tm_launch_seq{0};
 
 extern "C" {
 
@@ -1854,9 +2222,18 @@ int tm_tree_remove_nodes(const tm_store* s, const uint8_t* mask, void* stream) {
 int tm_sim_step(const tm_store* s, int flags, void* stream) {
     // the launch number (bits 8.. of the kernel's flags): what orders a game's wave and its collector workgroup, which
     // only ever hand over at kernel boundaries.  Any two launches that touch the same game differ in it.
-    static std::atomic<unsigned> launch_seq{0};
-    flags = (flags & 0xFF) | (int)(((launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
+    flags = (flags & 0xFF) | (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
     const dim3 grid((s->n_games + WPB - 1) / WPB + gc_blocks(s->n_games)), block(64 * WPB);
+    if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
+        hipLaunchKernelGGL(k_sim_step<true>, grid, block, WPB * sizeof(MtLds), (hipStream_t)stream, *s, flags);
+    else
+        hipLaunchKernelGGL(k_sim_step<false>, grid, block, 0, (hipStream_t)stream, *s, flags);
+    return TM_LAUNCH_CHECK();
+}
+int tm_gc_step(const tm_store* s, void* stream) {
+    // the collector workgroups alone, no time limit: one step of every collection under way
+    const int flags = TM_SIM_GC_FULL | (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
+    const dim3 grid(gc_blocks(s->n_games)), block(64 * WPB);
     if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
         hipLaunchKernelGGL(k_sim_step<true>, grid, block, WPB * sizeof(MtLds), (hipStream_t)stream, *s, flags);
     else
@@ -1868,7 +2245,7 @@ int tm_move_begin(const tm_store* s, int sims, void* stream) {
     return TM_LAUNCH_CHECK();
 }
 int tm_sims_remaining(const tm_store* s, int32_t* out, void* stream) {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(int32_t), (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(int32_t), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_sims_remaining, dim3((s->n_games + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s, out);
     return TM_LAUNCH_CHECK();
@@ -1894,7 +2271,8 @@ int tm_export_game(const tm_store* s, int game, int32_t* child, float* score, in
 extern "C" int tm_store_layout(int* out, int n) {
     int v[] = {(int)sizeof(tm_store), (int)offsetof(tm_store, gamma), (int)offsetof(tm_store, node_rec),
                (int)offsetof(tm_store, nq_table), (int)offsetof(tm_store, replay_count), (int)offsetof(tm_store, mt_state),
-               (int)offsetof(tm_store, node_child), (int)offsetof(tm_store, gc_slice_cycles)};
+               (int)offsetof(tm_store, node_child), (int)offsetof(tm_store, gc_slice_cycles),
+               (int)offsetof(tm_store, gc_part)};
     int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < m; ++i) out[i] = v[i];
     return m;

@@ -70,7 +70,7 @@ class TreeStore:
             free_node=z(G, N), free_obs=z(G, N), gs=z(G, 64), rng=z(G, 32), env_game=z(G, 16), env_line_stats=z(G, 4),
             trace=z(G, max_trace, 4), leaf=z(G, 32), eval_obs=z(G * eval_slots),
             eval_v=z(G * eval_slots, dtype=torch.float32), eval_var=z(G * eval_slots, dtype=torch.float32),
-            gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N),
+            gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N), gc_part=z(G, 128),
             replay_obs=z(G, max(replay_cap, 1), 12), replay_stat=z(G, max(replay_cap, 1), 4, dtype=torch.float32),
             replay_count=z(G),
             mt_state=z(G if kind in (KIND_VANILLA, KIND_VANILLA_C) else 1, 625),
@@ -88,7 +88,7 @@ class TreeStore:
         self.stats_buf = torch.zeros(G, 3, 7, dtype=torch.float32, device=dev)
         self.action_buf = torch.zeros(G, dtype=torch.int32, device=dev)
         self.eval_states = torch.zeros(G * eval_slots, 200, dtype=torch.int8, device=dev)
-        self._rem = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._rem = torch.zeros(2, dtype=torch.int32, device=dev)
         self._search = {}
         _lib.check(self.L.tm_pool_init(C.byref(s), _stream()), "tm_pool_init")
 
@@ -141,10 +141,15 @@ class TreeStore:
         _lib.check(self.L.tm_move_begin(C.byref(self.s), int(sims), _stream()), "tm_move_begin")
 
     def sims_remaining(self):
-        """Launches still needed before every game has used its quota (host sync): > 0 only when a game spent launches
-        collecting garbage instead of simulating."""
+        """(launches still needed before every game has used its quota, games whose collection is under way) - a host
+        sync; the first is > 0 only when a game spent launches collecting garbage instead of simulating."""
         _lib.check(self.L.tm_sims_remaining(C.byref(self.s), _p(self._rem), _stream()), "tm_sims_remaining")
-        return int(self._rem.item())
+        r = self._rem.cpu().numpy()
+        return int(r[0]), int(r[1])
+
+    def gc_step(self):
+        """One step of every garbage collection under way (collector workgroups only)."""
+        _lib.check(self.L.tm_gc_step(C.byref(self.s), _stream()), "tm_gc_step")
 
     def search(self, sims, model=None, n_sub=1, ev_every=0):
         """One move's search through the native launch loop (search.hip): `sims` simulations of every game, the leaf
@@ -166,9 +171,9 @@ class TreeStore:
         h = self._search.get((int(n_sub), int(ev_every)))
         if h is None:
             return None
-        out = (C.c_double * 7)()
-        self.L.tm_search_stats(h, out, 7, int(bool(reset)))
-        keys = ("runs", "tree_launches", "catchup_launches", "timed", "tree_ms_sum", "nn_ms_sum", "n_sub")
+        out = (C.c_double * 8)()
+        self.L.tm_search_stats(h, out, 8, int(bool(reset)))
+        keys = ("runs", "tree_launches", "catchup_launches", "timed", "tree_ms_sum", "nn_ms_sum", "n_sub", "gc_launches")
         return dict(zip(keys, list(out)))
 
     def sim_step(self, flags):
