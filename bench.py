@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--split", type=int, default=int(os.environ.get("TM_BENCH_SPLIT", "1")),
                     help="sub-batches of the rank's games on separate HIP streams (one sub-batch's tree kernel runs "
                     "under another's value-net kernels)")
-    ap.add_argument("--gc-slice-cycles", type=int, default=110000)
+    ap.add_argument("--gc-slice-cycles", type=int, default=150000)
     ap.add_argument("--online", action="store_true", help="harvest training tuples at GC and all-gather them every move")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)

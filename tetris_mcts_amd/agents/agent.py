@@ -39,7 +39,7 @@ class TreeAgent(Agent):
     def __init__(self, sims=100, max_nodes=500000, env=None, env_args=None, node_saver=None, projection=True,
                  min_visits=30, n_games=None, gamma=0.999, online=False, min_visits_to_store=10, replay_cap=0,
                  max_trace=1024, nq_size=1 << 20, reset_on_pool_exhaustion=True, n_sub=1, ev_every=0,
-                 gc_slice_cycles=110000, **kwargs):
+                 gc_slice_cycles=150000, **kwargs):
         super().__init__(**kwargs)
         if not projection:
             raise NotImplementedError("projection=False is broken in the reference itself (ValueSim.py:73-74)")
