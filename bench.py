@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STATE = 3803136            # conv1 82,944 + conv2 1,769,472 + conv3 1,032,192 + fc1 917,504 + fc_out 1,024
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def pmc_traffic(kernels, workload_key, fetch_scale=1.0):
@@ -71,6 +71,9 @@ def main():
                     "under another's value-net kernels)")
     ap.add_argument("--gc-slice-cycles", type=int, default=150000)
     ap.add_argument("--online", action="store_true", help="harvest training tuples at GC and all-gather them every move")
+    ap.add_argument("--steady-warmup", type=int, default=75, help="the steady-state window starts after this many moves")
+    ap.add_argument("--steady-steps", type=int, default=20, help="moves of the second, steady-state window (0: none)")
+    ap.add_argument("--steady-multi", action="store_true", help="measure the steady-state window in multi-GPU runs too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the N-process CPU baseline (0: all host cores, at most 128)")
@@ -84,8 +87,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    launched = "RANK" in os.environ      # torch.distributed.run: a process group (RCCL), even for one rank
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
 
@@ -102,8 +107,7 @@ def main():
     EV_EVERY = int(os.environ.get("TM_BENCH_EVENT_EVERY", "16"))
     env_args = ((20, 10), 1, 0, 0)
     model = Model_VV(backend=args.backend, seed=0)  # model_vv.Net() under torch.manual_seed(0) (random init)
-    base_seed = 20260925 + rank * G
-    game = Tetris(*env_args, seed=base_seed, n_games=G)
+    game = Tetris(*env_args, seed=tdist.game_seeds(20260925, G, rank), n_games=G)     # game g of rank r = game r*G + g of the job
     okw = dict(online=True, min_visits_to_store=10, replay_cap=16384) if args.online else dict(online=False)
     agent = getattr(agents, args.agent)(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=args.max_nodes,
                                         model=model, n_sub=NS, ev_every=EV_EVERY, gc_slice_cycles=args.gc_slice_cycles,
@@ -138,7 +142,7 @@ def main():
             n_local = keys.shape[0]
             ka, sa = tdist.all_gather_tuples(keys.view(torch.int32), stats)
             tot = torch.stack([local_sum, torch.tensor(n_local, device=dev, dtype=torch.int64)])
-            if world > 1:
+            if dist.is_initialized():
                 dist.all_reduce(tot)
             torch.cuda.synchronize()
             if timed:
@@ -151,46 +155,91 @@ def main():
                 gather["checksum_ok"] &= bool(int(tot[1].item()) == int(ka.shape[0]) and int(tot[0].item()) == int(got.item()))
 
     def counters():
-        return {k: S.counter(k) for k in ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL", "N_GC", "GC_SLICES", "N_DROPPED", "N_POOL_RESET")}
+        return {k: S.counter(k) for k in ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL", "N_GC", "GC_SLICES", "N_DROPPED", "N_POOL_RESET", "PREFIX_SUM")}
+
+    def measure(n_steps):
+        """Time exactly n_steps moves of every game (barrier + synchronize on both sides, max over ranks); counters are
+        summed over ranks."""
+        nonlocal episodes, lines
+        episodes, lines = 0, 0
+        torch.cuda.synchronize()
+        S.search_stats(NS, EV_EVERY, reset=True)
+        if world > 1:
+            dist.barrier()
+        c0 = counters()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            one_step(True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        c1 = counters()
+        ss = S.search_stats(NS, EV_EVERY, reset=False) or {}
+        err = int((S.errors() != 0).sum().item())
+        d = {k: c1[k] - c0[k] for k in c0}
+        tot = torch.tensor([elapsed, d["N_EXPAND"], d["N_SIMS"], d["TRACE_SUM"], d["N_EVAL"], episodes, lines, err,
+                            d["N_GC"], d["GC_SLICES"], d["N_DROPPED"], ss.get("catchup_launches", 0.0), d["N_POOL_RESET"],
+                            ss.get("gc_launches", 0.0), d["PREFIX_SUM"]], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = tot[:1].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            tot[0] = tmax[0]
+        keys = ("elapsed", "n_exp", "n_sims", "tr_sum", "n_eval", "episodes", "lines", "err", "n_gc", "gc_slices", "dropped",
+                "catchup", "pool_resets", "gc_launches", "prefix_sum")
+        r = dict(zip(keys, [float(x) for x in tot.cpu()]))
+        r["ss"], r["steps"] = ss, n_steps
+        return r
+
+    def kernel_figures(r):
+        """Per-launch durations of the two halves of a simulation step.  HIP events around every EV_EVERY-th simulation
+        give the SPLIT between value net and tree kernel; the events around the whole launch loop of every move give the
+        time per simulation the two must add up to (the sampled intervals each carry the cost of their own event records,
+        so their plain sum slightly exceeds the step)."""
+        ss = r["ss"]
+        if not ss.get("timed") or not ss.get("loop_sims"):
+            return None
+        nn_ev, tree_ev = ss["nn_ms_sum"] / ss["timed"], ss["tree_ms_sum"] / ss["timed"]
+        per_sim = ss["loop_ms_sum"] / ss["loop_sims"]
+        scale = per_sim / (nn_ev + tree_ev)
+        return dict(nn_ms=nn_ev * scale, tree_ms=tree_ev * scale, nn_event_ms=nn_ev, tree_event_ms=tree_ev, per_sim_ms=per_sim,
+                    timed=int(ss["timed"]))
 
     for _ in range(args.warmup):
         one_step(False)
-    torch.cuda.synchronize()
-    S.search_stats(NS, EV_EVERY, reset=True)
-    if world > 1:
-        dist.barrier()
-    c0 = counters()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    c1 = counters()
-    ss = S.search_stats(NS, EV_EVERY, reset=False) or {}
-    err = int((S.errors() != 0).sum().item())
+    head = measure(args.steps)
     max_trace = int(S.t["gs"][:, st.GS["MAX_TRACE"]].max().item())
-    d = {k: c1[k] - c0[k] for k in c0}
-    tot = torch.tensor([elapsed, d["N_EXPAND"], d["N_SIMS"], d["TRACE_SUM"], d["N_EVAL"], episodes, lines, err,
-                        d["N_GC"], d["GC_SLICES"], d["N_DROPPED"], ss.get("catchup_launches", 0.0), d["N_POOL_RESET"]],
-                       dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = tot[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        tot[0] = tmax[0]
-    elapsed, n_exp, n_sims, tr_sum, n_eval, episodes, lines, err, n_gc, gc_slices, dropped, catchup, pool_resets = [float(x) for x in tot.cpu()]
+    phase_kcycles = {k: float(S.t["gs"][:, st.GS[k]].float().mean().item()) / 1e3
+                     for k in ("CYC_BACK", "CYC_SELECT", "CYC_VERIFY", "CYC_EXPAND", "FIRST_MISS", "TRACE_LEN")}
+    steady = None
+    moves_done = args.warmup + args.steps
+    if args.steady_steps > 0 and not args.online and (world == 1 or args.steady_multi):
+        # the regime self-play lives in: trees fill their pools, games collect garbage every few moves (same games, later)
+        for _ in range(max(0, args.steady_warmup - moves_done)):
+            one_step(False)
+        first_move = max(args.steady_warmup, moves_done) + 1
+        steady = measure(args.steady_steps)
+        steady["first_move"] = first_move
 
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
-    mean_len = tr_sum / max(n_sims, 1.0)
+    elapsed, n_exp, n_sims, n_eval = head["elapsed"], head["n_exp"], head["n_sims"], head["n_eval"]
+    mean_len = head["tr_sum"] / max(n_sims, 1.0)
     cfg_idx = 1 if args.agent == "ValueSim" else 2
     workload_key = "%s G=%d sims=%d pool=%d warmup=%d steps=%d split=%d" % (args.agent, G, sims, args.max_nodes,
                                                                            args.warmup, args.steps, NS)
+
+    def gc_block(r):
+        return {"collections": int(r["n_gc"]), "collector_launches_x_games": int(r["gc_slices"]),
+                "launches_per_collection": (r["gc_slices"] / r["n_gc"]) if r["n_gc"] else None,
+                "catchup_launches": int(r["catchup"]), "catchup_launches_per_move": r["catchup"] / r["steps"] / world,
+                "collector_only_launches": int(r["gc_launches"]), "dropped_tuples": int(r["dropped"]),
+                "trees_restarted_pool_outgrown": int(r["pool_resets"])}
+
     out = {
         "metric": "mcts_node_expansions_per_sec",
         "value": n_exp / elapsed,
@@ -213,26 +262,41 @@ def main():
         "evaluated_states_per_sec": n_eval / elapsed,
         "mean_trace_len": mean_len,
         "max_trace_len": max_trace,
-        "episodes_finished": int(episodes),
-        "lines_cleared_per_episode": (lines / episodes) if episodes else None,
-        "lines_note": None if episodes else "no episode ends inside the timed window (random-init network, moves %d-%d "
+        "walk_levels_taken_over_from_the_previous_walk": head["prefix_sum"] / max(head["tr_sum"], 1.0),
+        "episodes_finished": int(head["episodes"]),
+        "lines_cleared_per_episode": (head["lines"] / head["episodes"]) if head["episodes"] else None,
+        "lines_note": None if head["episodes"] else "no episode ends inside the timed window (random-init network, moves %d-%d "
                       "of every game); the learning curve (lines cleared per episode vs training round) is "
                       "scripts/selfplay_online.py -> profiles/*_online_learning.jsonl" % (args.warmup + 1, args.warmup + args.steps),
-        "error_games": int(err),
+        "error_games": int(head["err"]),
         "walk_mispredicted_levels": S.counter("N_WALK_MISS") / max(S.counter("TRACE_SUM"), 1),
-        "gc": {"collections": int(n_gc), "slices": int(gc_slices), "catchup_launches": int(catchup), "collector_only_launches": int(ss.get("gc_launches", 0)),
-               "dropped_tuples": int(dropped), "trees_restarted_pool_outgrown": int(pool_resets)},
+        "gc": gc_block(head),
         "store_gib_per_gpu": S.nbytes() / 2**30,
-        "last_sim_phase_kcycles": {k: float(S.t["gs"][:, st.GS[k]].float().mean().item()) / 1e3
-                                   for k in ("CYC_BACK", "CYC_SELECT", "CYC_VERIFY", "CYC_EXPAND", "FIRST_MISS", "TRACE_LEN")},
+        "last_sim_phase_kcycles": phase_kcycles,
     }
+    if steady is not None:
+        kf = kernel_figures(steady)
+        out["steady_state"] = {
+            "what": "the same games later on: moves %d-%d, node pools full, every game collects garbage every few moves "
+                    "(reported beside the headline window, which SURVEY.md 8(d) defines as moves %d-%d)"
+                    % (steady["first_move"], steady["first_move"] + steady["steps"] - 1, args.warmup + 1, args.warmup + args.steps),
+            "value": steady["n_exp"] / steady["elapsed"], "unit": "node-expansions/s",
+            "ms_per_step": 1e3 * steady["elapsed"] / steady["steps"], "steps": steady["steps"],
+            "sims_per_sec": steady["n_sims"] / steady["elapsed"],
+            "mean_trace_len": steady["tr_sum"] / max(steady["n_sims"], 1.0),
+            "error_games": int(steady["err"]), "gc": gc_block(steady),
+            "tree_kernel_ms": kf["tree_ms"] if kf else None, "value_net_ms": kf["nn_ms"] if kf else None,
+        }
     if args.online:
         out["exchange"] = {"what": "all-gather of the (packed observation, value, variance, visit) tuples harvested at GC, "
                                    "once per move (tetris_mcts_amd/dist.py all_gather_tuples, backend nccl = RCCL)",
+                           "backend": dist.get_backend() if dist.is_initialized() else None,
+                           "collective_ran": bool(dist.is_initialized()),
                            "calls": gather["calls"], "tuples": gather["tuples"], "bytes": gather["bytes"],
                            "ms_total": gather["ms"], "multiset_check": gather["checksum_ok"]}
-    if ss.get("timed"):
-        nn_ms, tree_ms = ss["nn_ms_sum"] / ss["timed"], ss["tree_ms_sum"] / ss["timed"]
+    kf = kernel_figures(head)
+    if kf:
+        nn_ms, tree_ms = kf["nn_ms"], kf["tree_ms"]
         Gs = G / NS
         evals_per_launch = n_eval / max(n_sims, 1.0) * Gs
         flops = FLOP_PER_STATE * evals_per_launch
@@ -241,100 +305,136 @@ def main():
         a_gbs = bps * Gs / (tree_ms * 1e-3) / 1e9
         note = ("bytes/launch from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line); null when "
                 "that file was recorded for another workload" % PMC_FILE)
+        tnote = ("HIP events on the launch stream: around the whole launch loop of every move (%.4f ms per simulation = value "
+                 "net + tree kernel + launch gaps) and around every %d-th simulation for the split between the two (raw "
+                 "sampled intervals %.4f / %.4f ms, each carrying its own event records); avg_launch_ms x %d simulations <= "
+                 "ms_per_step by construction.  The rocprofv3 kernel trace of the same command is profiles/r03_kernel_stats_*.csv"
+                 % (kf["per_sim_ms"], EV_EVERY, kf["nn_event_ms"], kf["tree_event_ms"], sims))
         nn_roof = {"kernel": "value net forward (k_vn_conv + k_vn_fc1 + k_fc_out), per launch of %d request slots" % int(Gs * K),
                    "bound": "mfma", "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                    "frac": a_tf / PEAK_F32_MATRIX_TFLOPS,
                    "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1", "tmcts_vn::k_fc_out"], workload_key, 2.0)
                    if args.backend == "hip" else None,
                    "traffic_note": note + "; FETCH_SIZE x2 (wide streams)",
-                   "avg_launch_ms": nn_ms, "launches_timed": int(ss["timed"]), "events_every": EV_EVERY}
+                   "avg_launch_ms": nn_ms, "launches_timed": kf["timed"], "events_every": EV_EVERY, "timing_note": tnote}
         tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % int(Gs), "bound": "hbm",
                      "achieved": a_gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBPS,
                      "traffic": pmc_traffic(["tmcts::k_sim_step<false>"], workload_key),
                      "traffic_note": note + " (narrow scattered accesses: no gfx950 correction)",
-                     "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps, "launches_timed": int(ss["timed"]),
-                     "events_every": EV_EVERY,
-                     "timing_note": "HIP events on the sub-batch's own stream around every %d-th simulation; with %d "
-                                    "sub-batches the kernels of other streams share the device during the interval" % (EV_EVERY, NS)}
+                     "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps, "launches_timed": kf["timed"],
+                     "events_every": EV_EVERY, "timing_note": tnote}
         out["roofline"] = nn_roof if nn_ms >= tree_ms else tree_roof
         out["roofline_other"] = tree_roof if nn_ms >= tree_ms else nn_roof
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, model)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline (reported only): the reference's own compiled agent on this box's host cores
 # ---------------------------------------------------------------------------------------------------------------------
-def _cpu_worker(kind, sims, max_nodes, lp, seconds, seed, state_dict, q):
-    """One process = one game on one core, as the reference deploys them (cycle.sh:69-71)."""
+def _cpu_worker(kind, sims, max_nodes, lp, seconds, seed, state_dict, q, warm=5, timed=20, stride=1):
+    """One process = one game at a time on one core, as the reference deploys them (cycle.sh:69-71).  Like the GPU line it
+    times moves warm+1 .. warm+timed of fresh games (seeds seed, seed + stride, ...: trees of the same age, no garbage
+    collection, the reference never reaches its MAX_NODES EXCEEDED state), game after game until `seconds` are spent."""
     try:
         import numpy as np
         import torch
         torch.set_num_threads(1)
         from oracle import binding as B
-        if kind == "reference":
-            agent_mod = B.load_ref_native("agent")
-            if agent_mod is None:
-                q.put(None)
-                return
-            sys.path.insert(0, B.BUILD)
-            from pyTetris import Tetris as OTetris
-            from tetris_mcts_amd.model import Net
-            net = Net().eval()
-            net.load_state_dict(state_dict)
-            n_eval = [0]
+        from tetris_mcts_amd.model import Net
+        net = Net().eval()
+        net.load_state_dict(state_dict)
+        acc = dict(expansions=0, sims=0, evals=0, moves=0, seconds=0.0, games=0)
+        t_start = time.perf_counter()
 
-            def ev(obs):
-                x = torch.from_numpy(np.asarray(obs).astype(np.float32))
-                with torch.no_grad():
-                    y = net(x.reshape(-1, 1, 20, 10))
-                n_eval[0] += y.shape[0]
-                if lp:
-                    return [y[:, 0].tolist(), y[:, 1].tolist()]
-                return [float(y[0, 0]), float(y[0, 1])]
-            import ctypes
-            ctypes.CDLL("libc.so.6").srand(1)
-            g = OTetris((20, 10), 1, 0, 0, seed)
-            # expand() executions = evaluator calls: MCTSAgent evaluates exactly the non-terminal leaves it then expands
-            n_exp = [0]
+        def torch_eval(obs):
+            x = torch.from_numpy(np.asarray(obs).astype(np.float32))
+            with torch.no_grad():
+                return net(x.reshape(-1, 1, 20, 10))
 
-            def ev_count(obs):
-                n_exp[0] += 1
-                return ev(obs)
-            ag = agent_mod.MCTSAgent(sims, max_nodes, True, 0.999, False, ev_count, 0, lp)
-            ag.update_root(g)
+        def play_window(step, count):
+            """step() plays one move; count() returns the running (expansions, evaluated states)"""
+            for _ in range(warm):
+                step()
+            e0, v0 = count()
             t0 = time.perf_counter()
-            moves = 0
-            while time.perf_counter() - t0 < seconds:
-                g.play(int(ag.play()))
+            for _ in range(timed):
+                step()
+            acc["seconds"] += time.perf_counter() - t0
+            e1, v1 = count()
+            acc["expansions"] += e1 - e0; acc["evals"] += v1 - v0; acc["sims"] += timed * sims; acc["moves"] += timed; acc["games"] += 1
+
+        k = 0
+        while time.perf_counter() - t_start < seconds:
+            gseed = seed + k * stride
+            k += 1
+            if kind == "reference":
+                agent_mod = B.load_ref_native("agent")
+                if agent_mod is None:
+                    q.put(None)
+                    return
+                OTetris = B.oracle_pytetris().Tetris       # by path: the product has a module named pyTetris as well
+                import ctypes
+                ctypes.CDLL("libc.so.6").srand(1)
+                g = OTetris((20, 10), 1, 0, 0, gseed)
+                cnt = [0, 0]       # expand() executions = evaluator calls (MCTSAgent evaluates exactly the leaves it expands); states
+
+                def ev(obs, cnt=cnt):
+                    y = torch_eval(obs)
+                    cnt[0] += 1; cnt[1] += y.shape[0]
+                    return [y[:, 0].tolist(), y[:, 1].tolist()] if lp else [float(y[0, 0]), float(y[0, 1])]
+                ag = agent_mod.MCTSAgent(sims, max_nodes, True, 0.999, False, ev, 0, lp)
                 ag.update_root(g)
-                moves += 1
-                if g.end:
-                    g.reset()
+
+                def step(g=g, ag=ag):
+                    g.play(int(ag.play()))
                     ag.update_root(g)
-            dt = time.perf_counter() - t0
-            q.put(dict(expansions=n_exp[0], sims=moves * sims, evals=n_eval[0], moves=moves, seconds=dt))
-        else:
-            params = torch.cat([state_dict[k].reshape(-1).float() for k in state_dict]).numpy()
-            g = B.Game(seed=seed)
-            a = B.Agent(1 if lp else 0, max_nodes=max_nodes, evaluator="valuenet", params=params)
-            a.update_root(g)
-            t0 = time.perf_counter()
-            moves = 0
-            while time.perf_counter() - t0 < seconds:
-                g.play(a.play(sims))
+                    if g.end:
+                        g.reset()
+                        ag.update_root(g)
+                play_window(step, lambda cnt=cnt: (cnt[0], cnt[1]))
+            elif kind == "reference_py":
+                # the reference's own Python ValueSim / ValueSimLP (agents/ValueSim.py) - needs the reference sources
+                from oracle import ref_shims
+                ref_shims.install()
+                ref_shims.srand(1)
+                cnt = [0, 0]
+
+                def ev(states, cnt=cnt):
+                    y = torch_eval(states)
+                    cnt[0] += 1; cnt[1] += y.shape[0]
+                    return y[:, 0].numpy(), y[:, 1].numpy()
+                ag = ref_shims.make_agent("ValueSimLP" if lp else "ValueSim", sims, evaluator=ev)
+                g = B.oracle_pytetris().Tetris((20, 10), 1, 0, 0, gseed)
+                ag.update_root(g)
+
+                def step(g=g, ag=ag):
+                    g.play(int(ag.play()))
+                    ag.update_root(g)
+                    if g.end:
+                        g.reset()
+                        ag.update_root(g)
+                play_window(step, lambda cnt=cnt: (cnt[0], cnt[1]))
+            else:
+                params = torch.cat([state_dict[kk].reshape(-1).float() for kk in state_dict]).numpy()
+                g = B.Game(seed=gseed)
+                a = B.Agent(1 if lp else 0, max_nodes=max_nodes, evaluator="valuenet", params=params)
                 a.update_root(g)
-                moves += 1
-                if g.end:
-                    g.reset()
+
+                def step(g=g, a=a):
+                    g.play(a.play(sims))
                     a.update_root(g)
-            dt = time.perf_counter() - t0
-            q.put(dict(expansions=a.n_expand, sims=a.n_sims, evals=a.n_expand, moves=moves, seconds=dt))
+                    if g.end:
+                        g.reset()
+                        a.update_root(g)
+                play_window(step, lambda a=a: (a.n_expand, a.n_expand))
+        q.put(acc)
     except Exception as e:  # reported, never fatal for the benchmark line
-        q.put(dict(error=repr(e)))
+        import traceback
+        q.put(dict(error=repr(e) + " " + traceback.format_exc()[-300:]))
 
 
 def _cpu_run(kind, nproc, args, state_dict, seconds):
@@ -342,13 +442,14 @@ def _cpu_run(kind, nproc, args, state_dict, seconds):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     lp = args.agent != "ValueSim"
-    procs = [ctx.Process(target=_cpu_worker, args=(kind, args.sims, args.max_nodes, lp, seconds, 20260925 + i, state_dict, q))
+    procs = [ctx.Process(target=_cpu_worker, args=(kind, args.sims, args.max_nodes, lp, seconds, 20260925 + i, state_dict, q,
+                                                   args.warmup, args.steps, nproc))
              for i in range(nproc)]
     t0 = time.perf_counter()
     for p in procs:
         p.start()
     # every worker reports once; one that died (or hangs) must not hold the benchmark line up: a fixed deadline
-    res, deadline = [], time.perf_counter() + seconds + 120.0
+    res, deadline = [], time.perf_counter() + 3.0 * seconds + 180.0      # (a game's window is finished once it is begun)
     while len(res) < len(procs) and time.perf_counter() < deadline:
         try:
             res.append(q.get(timeout=2.0))
@@ -364,10 +465,13 @@ def _cpu_run(kind, nproc, args, state_dict, seconds):
     errs = [r["error"] for r in res if r and "error" in r]
     if not ok:
         return None, errs
+    ok = [r for r in ok if r["seconds"] > 0]
+    if not ok:
+        return None, errs
     rate = sum(r["expansions"] / r["seconds"] for r in ok)
     return dict(value=rate, procs_ok=len(ok), expansions=sum(r["expansions"] for r in ok), sims=sum(r["sims"] for r in ok),
                 sims_per_sec=sum(r["sims"] / r["seconds"] for r in ok), moves=sum(r["moves"] for r in ok),
-                seconds_each=seconds, wall=wall), errs
+                games=sum(r["games"] for r in ok), seconds_each=seconds, wall=wall), errs
 
 
 def cpu_baseline(args, model):
@@ -398,7 +502,8 @@ def cpu_baseline(args, model):
         ncpu_aff = ncpu
     usable = int(min(ncpu_aff, quota) if quota else ncpu_aff)
     nproc = args.cpu_procs or max(1, min(usable - 1, 128))     # one core stays with this process
-    sample = "1 game per process x %d sims/move from a fresh game (seed 20260925+i), pool %d, same network weights, %.0f s per process"
+    sample = ("per process: fresh games (seed 20260925 + i, + n_procs, ...), %d sims/move, pool %d, the GPU line's own window - moves "
+              "%d-%d of every game timed, the first %d untimed - game after game for %.0f s; same network weights")
     kind = "reference"
     one, errs = _cpu_run(kind, 1, args, sd, args.cpu_seconds)
     if one is None:
@@ -408,13 +513,25 @@ def cpu_baseline(args, model):
         return {"value": None, "unit": "node-expansions/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % errs[:1]}
     many, errs2 = _cpu_run(kind, nproc, args, sd, args.cpu_seconds) if nproc > 1 else (None, [])
     out = {"value": (many or one)["value"], "unit": "node-expansions/s", "cores": (many["procs_ok"] if many else 1), "kind": kind,
-           "sample": (sample % (args.sims, args.max_nodes, args.cpu_seconds)) +
+           "sample": (sample % (args.sims, args.max_nodes, args.warmup + 1, args.warmup + args.steps, args.warmup, args.cpu_seconds)) +
                      ("; the reference's compiled MCTSAgent (agent.cpp, LP=%s) + torch CPU Net, 1 thread per process" % (args.agent != "ValueSim")
                       if kind == "reference" else "; oracle C restatement incl. its fp32 value net"),
            "host_cpus": ncpu, "cpu_affinity": ncpu_aff, "cgroup_cpu_quota": quota,
-           "one_core": {"value": one["value"], "sims_per_sec": one["sims_per_sec"], "moves": one["moves"]},
+           "one_core": {"value": one["value"], "sims_per_sec": one["sims_per_sec"], "moves": one["moves"], "games": one["games"]},
            "all_cores": None if many is None else {"value": many["value"], "procs": many["procs_ok"], "sims_per_sec": many["sims_per_sec"],
-                                                   "per_core": many["value"] / max(many["procs_ok"], 1), "wall_s": many["wall"]}}
+                                                   "per_core": many["value"] / max(many["procs_ok"], 1), "wall_s": many["wall"],
+                                                   "games": many["games"]}}
+    # the agent BASELINE configs[1] names, the reference's Python ValueSim: runs only where the reference sources are
+    if os.path.isdir(os.environ.get("TETRIS_MCTS_REFERENCE", "/root/reference")):
+        py, errs3 = _cpu_run("reference_py", 1, args, sd, args.cpu_seconds)
+        out["python_agent_one_core"] = (None if py is None else
+                                        {"value": py["value"], "sims_per_sec": py["sims_per_sec"], "moves": py["moves"], "games": py["games"],
+                                         "what": "agents/%s.py of the reference, imported unmodified (oracle/ref_shims.py), same window" % args.agent})
+        errs2 = errs2 + errs3
+    else:
+        out["python_agent_one_core"] = None
+        out["python_agent_note"] = ("the reference's Python agent needs the reference sources, which are not on this box; timed in "
+                                    "the build container: DESIGN.md section 5")
     if errs or errs2:
         out["worker_errors"] = (errs + errs2)[:3]
     return out

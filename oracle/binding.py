@@ -248,12 +248,33 @@ class Agent:
             pass
 
 
+def oracle_pytetris():
+    """The oracle's compiled `pyTetris` extension (oracle/_build/pyTetris*.so), loaded by path: the product ships a
+    module of the same name (the reference's import line must resolve to the GPU engine), so `import pyTetris` may
+    return either one depending on sys.path and on what the process imported first.  Checker code never relies on
+    that: it asks here.  sys.modules is left alone."""
+    import importlib.util
+    import sysconfig
+    path = os.path.join(BUILD, "pyTetris" + sysconfig.get_config_var("EXT_SUFFIX"))
+    m = sys.modules.get("pyTetris")
+    if m is not None and os.path.abspath(getattr(m, "__file__", "") or "") == os.path.abspath(path):
+        return m
+    cached = getattr(oracle_pytetris, "_mod", None)
+    if cached is None:
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: make -C oracle own" % path)
+        spec = importlib.util.spec_from_file_location("pyTetris", path)
+        cached = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(cached)
+        oracle_pytetris._mod = cached
+    return cached
+
+
 def load_ref_native(name):
     """Import the reference's own compiled module (oracle/_ref/<name>*.so): 'core' or 'agent'."""
     import importlib.util
     import sysconfig
-    if BUILD not in sys.path:
-        sys.path.insert(0, BUILD)  # the agent module needs `pyTetris` types registered
+    oracle_pytetris()          # the agent module needs the oracle's Tetris type registered (pybind, per interpreter)
     path = os.path.join(REFOUT, name + sysconfig.get_config_var("EXT_SUFFIX"))
     if not os.path.exists(path):
         return None

@@ -28,8 +28,6 @@ def install():
     if not available():
         raise RuntimeError("reference tree not present at %s" % REF)
     binding.build(ref=True)
-    if binding.BUILD not in sys.path:
-        sys.path.insert(0, binding.BUILD)
     if REF not in sys.path:
         sys.path.insert(0, REF)
     if "numba" not in sys.modules:
@@ -47,7 +45,9 @@ def install():
         ci = types.ModuleType("cppimport")
         ci.imp = lambda name: None
         sys.modules["cppimport"] = ci
-    import pyTetris  # noqa: F401  (registers the Tetris type before the native agent module loads)
+    # The reference's own modules say `from pyTetris import Tetris`: in a process that runs them, that name is the oracle's
+    # engine - explicitly, whatever was imported before (the product has a module of the same name).
+    sys.modules["pyTetris"] = binding.oracle_pytetris()
     import agents  # namespace package under /root/reference
     import agents.cppmodule
     for name in ("core", "agent"):
@@ -77,7 +77,7 @@ def make_agent(name, sims, max_nodes=None, evaluator=None, **kwargs):
     """
     install()
     from importlib import import_module
-    from pyTetris import Tetris
+    Tetris = binding.oracle_pytetris().Tetris
     mod = import_module("agents." + name)
     cls = getattr(mod, name)
     env_args = kwargs.pop("env_args", ((20, 10), 1, 0, 0))

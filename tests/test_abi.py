@@ -122,3 +122,25 @@ def test_the_product_never_touches_the_oracle():
         return users
     assert oracle_users(os.path.join(ROOT, "bench.py")) <= {"_cpu_worker", "cpu_baseline"}
     assert oracle_users(os.path.join(ROOT, "__graft_entry__.py")) <= {"smoke"}
+
+
+def test_oracle_engine_is_loaded_by_path_whatever_pyTetris_means(oracle):
+    """The product ships a module named `pyTetris` (the reference's import line must resolve to the GPU engine) and so
+    does the oracle's build directory.  Checker code asks oracle.binding.oracle_pytetris() and gets the compiled oracle
+    extension even when the product's module was imported first; sys.modules is not touched."""
+    import importlib
+    import sys
+    sys.modules.pop("pyTetris", None)
+    sys.path.insert(0, ROOT)
+    try:
+        prod = importlib.import_module("pyTetris")
+        assert "oracle" not in (prod.__file__ or "")
+        mod = oracle.oracle_pytetris()
+        assert mod is not prod and mod.__file__.startswith(oracle.BUILD)
+        assert sys.modules["pyTetris"] is prod
+        g = mod.Tetris((20, 10), 1, 0, 0, 5)
+        g.play(3)
+        assert g.score >= 0 and oracle.oracle_pytetris() is mod
+    finally:
+        sys.path.remove(ROOT)
+        sys.modules.pop("pyTetris", None)

@@ -142,3 +142,78 @@ def test_data_parallel_training_gloo_world2():
     assert single["iters"] == res[0][2]
     assert np.abs(flat - start).max() > 1e-3                       # the run moved the weights ...
     assert np.abs(flat - res[0][1]).max() < 2e-5                   # ... and both runs moved them the same way
+
+
+# ---- a game's trajectory does not depend on the number of ranks -------------------------------------------------------
+_JOB_GAMES, _JOB_BASE, _JOB_MOVES, _JOB_SIMS = 8, 20260925, 5, 60
+
+
+def _play_shard(oracle_binding, rank, world):
+    """The games of `rank` in a job of `world` ranks (dist.game_seeds: game g of rank r = game r * G + g of the job), each
+    with its own oracle agent: per game the list of (action, score) over the first moves."""
+    from tetris_mcts_amd import dist as tdist
+    per = _JOB_GAMES // world
+    out = {}
+    for g, seed in enumerate(tdist.game_seeds(_JOB_BASE, per, rank)):
+        game = oracle_binding.Game(seed=int(seed))
+        agent = oracle_binding.Agent(0, max_nodes=4000)       # ValueSim numerics, hash evaluator
+        agent.update_root(game)
+        traj = []
+        for _ in range(_JOB_MOVES):
+            a = agent.play(_JOB_SIMS)
+            game.play(a)
+            agent.update_root(game)
+            traj.append((int(a), int(game.score)))
+        out[rank * per + g] = traj
+    return out
+
+
+def _traj_worker(rank, world, port, q):
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import binding as B
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = _play_shard(B, rank, world)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    q.put((rank, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trajectories_do_not_depend_on_world_size(oracle):
+    """8 games as one process and as 2 ranks of 4 (gloo): every game - identified by its index in the job - plays the
+    same actions to the same scores.  (The reference's agents run on the CPU oracle here; the GPU engine is held to the
+    oracle game by game in the -m gpu tests, so the property carries over.)"""
+    single = _play_shard(oracle, 0, 1)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_traj_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, gathered in res:
+        merged = {}
+        for part in gathered:
+            merged.update(part)
+        assert sorted(merged) == list(range(_JOB_GAMES))
+        assert merged == single, rank
+
+
+def test_data_parallel_training_rejects_unequal_shards():
+    """batch_size must split evenly over the ranks: checked before any collective is issued."""
+    import pytest
+    from tetris_mcts_amd import train as T
+    T.check_data_parallel_batch(7, 1)
+    T.check_data_parallel_batch(1024, 8)
+    with pytest.raises(ValueError):
+        T.check_data_parallel_batch(1025, 8)
+    with pytest.raises(ValueError):
+        T.check_data_parallel_batch(4, 8)       # a rank would get an empty shard

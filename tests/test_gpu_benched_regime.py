@@ -5,7 +5,7 @@ launch loop (search.hip) with sub-batches on separate streams.
 
 Covered on purpose, with assertions that they really happened:
   * traces longer than 128 nodes (two flushes of the 64-entry LDS trace buffer, three chunks of the backup),
-  * a garbage collection at the full 100 000-entry pool, run in slices with the catch-up launches that follow,
+  * a garbage collection at the full 100 000-entry pool, by the collector workgroups, with the catch-up launches that follow,
   * sampled games of a real 4096-game batch (results must not depend on the batch a game runs in).
 The oracle games run in parallel threads (liboracle releases the GIL)."""
 from concurrent.futures import ThreadPoolExecutor
@@ -109,19 +109,24 @@ def test_traces_beyond_128_and_a_collection_at_the_full_pool(oracle):
     assert gs[0, 19] > 128, gs[0, 19]                 # TM_GS_MAX_TRACE: > 2 LDS flushes, 3 backup chunks
     assert gs[1, 9] >= 1                              # TM_GS_N_GC: the collection happened ...
     assert gs[1, 24] > 50000                          # ... with most of the pool reachable
-    assert gs[1, 38] > gs[1, 9]                       # TM_GS_GC_SLICES: ... in more than one slice per collection
+    assert gs[1, 38] > 5 * gs[1, 9]                   # TM_GS_GC_SLICES: ... over several launches (the steps of tree.hip)
     ss = agent.store.search_stats(1, 0)
     assert ss["catchup_launches"] > 0                 # the collecting game caught up after the regular launches
 
 
-def test_sampled_games_of_a_real_4096_game_batch(oracle):
-    """BASELINE configs[1] itself: 4096 games x 500 sims/move, four sub-batches; games 0, 1337 and 4095 against their
-    own oracles for 6 moves (a game's results must not depend on the batch or the sub-batch it runs in)."""
+@pytest.mark.parametrize("name,moves,n_sub", [("ValueSim", 6, 4), ("ValueSimLP", 4, 1)])
+def test_sampled_games_of_a_real_4096_game_batch(oracle, name, moves, n_sub):
+    """BASELINE configs[1] and configs[2] themselves: 4096 games x 500 sims/move (ValueSim: four sub-batches; ValueSimLP:
+    28 672 request slots, seven per game, one batch); games 0, 1337 and 4095 against their own oracles (a game's results
+    must not depend on the batch or the sub-batch it runs in)."""
     import torch
     seeds = BASE_SEED + np.arange(4096)
-    agent, orc = _run(oracle, "ValueSim", seeds, sample=[0, 1337, 4095], moves=6, n_sub=4, check_tree=True)
+    agent, orc = _run(oracle, name, seeds, sample=[0, 1337, 4095], moves=moves, n_sub=n_sub, check_tree=True)
     gs = agent.store.t["gs"]
-    assert (gs[:, 8] == 6 * 500).all()               # every game ran every simulation
+    assert (gs[:, 8] == moves * 500).all()           # every game ran every simulation
     assert int(gs[:, 6].abs().sum().item()) == 0
+    if name == "ValueSimLP":
+        assert agent.store.eval_slots == 7 and agent.store.t["eval_obs"].numel() == 28672
+        assert int(gs[:, 17].sum().item()) > 3 * int(gs[:, 7].sum().item())     # several evaluated states per expansion
     del agent
     torch.cuda.empty_cache()

@@ -26,10 +26,14 @@ struct tm_search {
     std::vector<tm_store> sub;
     std::vector<int> first;
     std::vector<hipStream_t> streams;
-    hipEvent_t ev_start;
+    hipEvent_t ev_start = nullptr;
     std::vector<hipEvent_t> ev_done;
-    int32_t* rem_dev;
-    int32_t* rem_host;
+    int32_t* rem_dev = nullptr;
+    int32_t* rem_host = nullptr;
+    // HIP events around the regular launches of a move (sub-batch 0's stream): the time the per-kernel figures must add up to
+    hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
+    double loop_ms = 0;
+    long long loop_sims = 0;
     // HIP-event timing of every `ev_every`-th simulation of sub-batch 0, on the stream the kernels run on
     int ev_every;
     std::vector<hipEvent_t> ev;      // triples: before value net, after value net (= before tree), after tree
@@ -77,6 +81,8 @@ int tm_store_slice(const tm_store* s, int first, int n, tm_store* out) {
     return 0;
 }
 
+void tm_search_destroy(tm_search* h);
+
 int tm_search_create(tm_search** out, const tm_store* s, int n_sub, int ev_every) {
     if (n_sub < 1 || n_sub > 64 || n_sub > s->n_games) return (int)hipErrorInvalidValue;
     tm_search* h = new tm_search();
@@ -87,6 +93,8 @@ int tm_search_create(tm_search** out, const tm_store* s, int n_sub, int ev_every
     h->ev_used = 0;
     h->tree_ms = h->nn_ms = 0;
     h->n_timed = h->n_runs = h->extra_launches = h->launches = h->gc_launches = 0;
+    // every failure leaves through the same door: whatever exists by then is released by tm_search_destroy
+    auto fail = [&](int e) { tm_search_destroy(h); return e; };
     // sub-batch boundaries on multiples of 4 games (one workgroup of the tree kernel = 4 games)
     const int G = s->n_games;
     int per = ((G + n_sub - 1) / n_sub + 3) & ~3;
@@ -95,29 +103,33 @@ int tm_search_create(tm_search** out, const tm_store* s, int n_sub, int ev_every
         if (n < 0) n = 0;
         tm_store t;
         int e = tm_store_slice(s, f, n, &t);
-        if (e) { delete h; return e; }
+        if (e) return fail(e);
         h->sub.push_back(t);
         h->first.push_back(f);
         f += n;
     }
     hipError_t e = hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming);
-    if (e != hipSuccess) { delete h; return (int)e; }
+    if (e != hipSuccess) return fail((int)e);
+    e = hipEventCreate(&h->ev_loop0);
+    if (e != hipSuccess) return fail((int)e);
+    e = hipEventCreate(&h->ev_loop1);
+    if (e != hipSuccess) return fail((int)e);
     for (int k = 0; k < n_sub; ++k) {
         hipStream_t st = nullptr;
         if (h->own_streams) {
             e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-            if (e != hipSuccess) return (int)e;
+            if (e != hipSuccess) return fail((int)e);
         }
         h->streams.push_back(st);
         hipEvent_t d;
         e = hipEventCreateWithFlags(&d, hipEventDisableTiming);
-        if (e != hipSuccess) return (int)e;
+        if (e != hipSuccess) return fail((int)e);
         h->ev_done.push_back(d);
     }
     e = hipMalloc(&h->rem_dev, sizeof(int32_t) * 2 * n_sub);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) return fail((int)e);
     e = hipHostMalloc(&h->rem_host, sizeof(int32_t) * 2 * n_sub, hipHostMallocDefault);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) return fail((int)e);
     *out = h;
     return 0;
 }
@@ -127,7 +139,9 @@ void tm_search_destroy(tm_search* h) {
     for (auto st : h->streams) if (st && h->own_streams) (void)hipStreamDestroy(st);
     for (auto e : h->ev_done) (void)hipEventDestroy(e);
     for (auto e : h->ev) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(h->ev_start);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_loop0) (void)hipEventDestroy(h->ev_loop0);
+    if (h->ev_loop1) (void)hipEventDestroy(h->ev_loop1);
     if (h->rem_dev) (void)hipFree(h->rem_dev);
     if (h->rem_host) (void)hipHostFree(h->rem_host);
     delete h;
@@ -157,6 +171,7 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
         return tm_valuenet_forward_requests(vn_params, vn_prepared, &h->sub[k], scr, st[k]);
     };
     h->ev_used = 0;
+    TM_TRY(hipEventRecord(h->ev_loop0, st[0]));
     for (int k = 0; k < K; ++k) TM_TRY(step(k));
     for (int i = 0; i < sims; ++i) {
         const bool timed = h->ev_every > 0 && (i % h->ev_every) == 0;
@@ -178,6 +193,7 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
             if (e3) TM_TRY(hipEventRecord(e3[2], st[k]));
         }
     }
+    TM_TRY(hipEventRecord(h->ev_loop1, st[0]));
     // catch-up: games that spent launches collecting garbage still owe simulations.  Collections still under way are
     // finished first, by collector-only launches (tm_gc_step: a step of every collection each, no simulation, no evaluator).
     for (;;) {
@@ -214,18 +230,27 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
             h->n_timed += 1;
         }
     }
+    {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev_loop0, h->ev_loop1) == hipSuccess) { h->loop_ms += ms; h->loop_sims += sims; }
+    }
     h->n_runs += 1;
     return 0;
 }
 
-// out[0..7] = runs, tree-kernel launches, catch-up launches, timed samples, sum of tree-kernel ms, sum of value-net ms,
-// sub-batches, collector-only launches; the sums are over the timed samples (sub-batch 0, every ev_every-th simulation)
+// out[0..9] = runs, tree-kernel launches, catch-up launches, timed samples, sum of tree-kernel ms, sum of value-net ms,
+// sub-batches, collector-only launches, sum of the regular launch loops' ms (HIP events around sims x (value net, tree
+// kernel) of sub-batch 0's stream), simulations in those loops; the per-kernel sums are over the timed samples (sub-batch
+// 0, every ev_every-th simulation)
 int tm_search_stats(tm_search* h, double* out, int n, int reset) {
-    double v[8] = {(double)h->n_runs, (double)h->launches, (double)h->extra_launches, (double)h->n_timed, h->tree_ms,
-                   h->nn_ms, (double)h->n_sub, (double)h->gc_launches};
-    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
-    if (reset) { h->tree_ms = h->nn_ms = 0; h->n_timed = h->n_runs = h->extra_launches = h->launches = h->gc_launches = 0; }
-    return 8;
+    double v[10] = {(double)h->n_runs, (double)h->launches, (double)h->extra_launches, (double)h->n_timed, h->tree_ms,
+                    h->nn_ms, (double)h->n_sub, (double)h->gc_launches, h->loop_ms, (double)h->loop_sims};
+    for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+    if (reset) {
+        h->tree_ms = h->nn_ms = h->loop_ms = 0;
+        h->n_timed = h->n_runs = h->extra_launches = h->launches = h->gc_launches = h->loop_sims = 0;
+    }
+    return 10;
 }
 
 }  // extern "C"

@@ -18,6 +18,14 @@ def shard_range(n_total, rank, world):
     return start, base + (1 if rank < rem else 0)
 
 
+def game_seeds(base_seed, games_per_rank, rank, world=None):
+    """Environment seeds of one rank's games: game g of rank r is game r * games_per_rank + g of the job, seeded
+    base_seed + that index - a game's whole trajectory depends on its index in the job only, never on how many ranks
+    the job has or on which of them it runs (tests/test_dist.py)."""
+    import numpy as np
+    return int(base_seed) + int(rank) * int(games_per_rank) + np.arange(int(games_per_rank), dtype=np.int64)
+
+
 def rank(group=None):
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
@@ -38,9 +46,9 @@ def all_gather_tuples(obs_keys, stats, group=None):
     visit, 0.  Returns (obs_keys_all, stats_all) = the concatenation over ranks in rank order (identical on every
     rank).  One count all-gather (8 B/rank) + one padded payload all-gather (64 B/tuple).
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return obs_keys, stats
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group)       # (a one-rank group still goes through the collective: same code path as N ranks)
     dev = obs_keys.device
     n = torch.tensor([obs_keys.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]

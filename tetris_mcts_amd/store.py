@@ -171,9 +171,10 @@ class TreeStore:
         h = self._search.get((int(n_sub), int(ev_every)))
         if h is None:
             return None
-        out = (C.c_double * 8)()
-        self.L.tm_search_stats(h, out, 8, int(bool(reset)))
-        keys = ("runs", "tree_launches", "catchup_launches", "timed", "tree_ms_sum", "nn_ms_sum", "n_sub", "gc_launches")
+        out = (C.c_double * 10)()
+        self.L.tm_search_stats(h, out, 10, int(bool(reset)))
+        keys = ("runs", "tree_launches", "catchup_launches", "timed", "tree_ms_sum", "nn_ms_sum", "n_sub", "gc_launches",
+                "loop_ms_sum", "loop_sims")
         return dict(zip(keys, list(out)))
 
     def sim_step(self, flags):

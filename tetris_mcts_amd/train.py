@@ -94,6 +94,14 @@ def validation_loss(net, data, weighted, chunk=1024):
     return mean, math.sqrt(max(acc2 / tot_w - mean * mean, 0.0))
 
 
+def check_data_parallel_batch(batch_size, world):
+    """Equal shards only: the average of the ranks' shard means is then the batch mean (with unequal shards it is not, and
+    a rank with an empty shard would feed NaN into the all-reduce)."""
+    if world > 1 and batch_size % world:
+        raise ValueError("data-parallel training needs batch_size (%d) to be a multiple of the number of ranks (%d)"
+                         % (batch_size, world))
+
+
 def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validation_fraction=0.1,
                sample_replacement=True, oversampling=False, weighted=True, early_stopping=True, early_stopping_patience=10,
                early_stopping_threshold=1.0, shuffle=False, max_iters=100000, grad_clip=0.0, save=None, load=None,
@@ -110,6 +118,7 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
     import torch.distributed as tdist
     world = tdist.get_world_size(group) if (data_parallel and tdist.is_available() and tdist.is_initialized()) else 1
     my_rank = tdist.get_rank(group) if world > 1 else 0
+    check_data_parallel_batch(batch_size, world)
     if world > 1 and generator is None:
         seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(data[0].device)
         tdist.broadcast(seed, src=tdist.get_global_rank(group, 0) if group is not None else 0, group=group)
