@@ -33,7 +33,7 @@ extern "C" {
 #define TM_KIDS_DW 8       /* raw children row: child[7] in action order + pad */
 #define TM_GS_DW 64        /* per-game control block */
 #define TM_LEAF_DW 32      /* per-game leaf hand-off between the front and back halves of a simulation */
-#define TM_GC_PART_DW 128   /* per-game scratch of a collection: (free nodes, free observations, harvested tuples) per collector workgroup */
+#define TM_GC_PART_DW 192   /* per-game scratch of a collection: (free nodes, free observations, harvested tuples) per collector workgroup */
 #define TM_VALUENET_PARAMS 478342
 #define TM_VALUENET_SCRATCH 9728       /* floats of scratch per state, tm_valuenet_forward_plain */
 #define TM_VALUENET_SCRATCH_MFMA 2048  /* floats of scratch per state, tm_valuenet_forward */

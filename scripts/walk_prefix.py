@@ -42,9 +42,11 @@ for m in range(a.moves):
     rec["kcycles_mean"] = {k: float(v.mean()) / 1e3 for k, v in cyc.items()}
     rec["kcycles_p99"] = {k: float(np.percentile(v, 99)) / 1e3 for k, v in cyc.items()}
     rec["kcycles_total_mean_p99_max"] = [float(tot.mean()) / 1e3, float(np.percentile(tot, 99)) / 1e3, float(tot.max()) / 1e3]
-    rec["slowest_games"] = [dict(g=int(g), len=int(ln[g]), k0=int(fm[g]), **{k: int(v[g]) // 1000 for k, v in cyc.items()}) for g in slow]
+    rec["slowest_games"] = [dict(g=int(g), len=int(ln[g]), k0=int(fm[g]), pool_full=int(gs[g, 44]), pending=int(gs[g, 5]), nfree=int(gs[g, 2]),
+                                 gc_phase=int(gs[g, 32] & 15), **{k: int(v[g]) // 1000 for k, v in cyc.items()}) for g in slow]
+    rec["pool_full_games"] = int((gs[:, 44] != 0).sum()); rec["collecting_games"] = int(((gs[:, 32] & 15) != 0).sum())
     out.append(rec)
-    print(json.dumps(rec), flush=True)
+    if m >= a.moves - 3: print(json.dumps(rec), flush=True)
     game.play(act)
     agent.update_root(game)
     ended = np.atleast_1d(game.end)

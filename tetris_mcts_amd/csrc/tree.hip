@@ -297,13 +297,25 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     int nfree = has_gsv ? GSV(gsv, TM_GS_NFREE_NODE) : P.gs()[TM_GS_NFREE_NODE];
     if (__any(full)) { if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_TABLE); }
     if (cnt > nfree) {
-        // Pool exhausted: the reference reclaims unreachable nodes at exactly this pop
-        // (agents/agent.py:96-97).  Candidates before the exhausting one are inserted first, exactly as
-        // the sequential reference does, then the wave collects garbage and the rest is retried.
-        // Handled by the caller-visible slow path below.
-        r_idx = -1;
-        r_obs = nfree;  // tells the caller how many can still be taken
-        return;
+        const bool no_more_gc = has_gsv && (GSV(gsv, TM_GS_GC_RETRY) != 0 || GSV(gsv, TM_GS_POOL_FULL) != 0);
+        if (!no_more_gc) {
+            // Pool exhausted: the reference reclaims unreachable nodes at exactly this pop
+            // (agents/agent.py:96-97).  Candidates before the exhausting one are inserted first, exactly as
+            // the sequential reference does, then a collection is requested and the rest is retried.
+            // Handled by the caller-visible slow path below.
+            r_idx = -1;
+            r_obs = nfree;  // tells the caller how many can still be taken
+            return;
+        }
+        // Exhausted although everything unreachable has just been reclaimed (or nothing can be before the root moves): the
+        // reachable tree has outgrown the pool (the reference prints MAX_NODES EXCEEDED and runs into undefined behaviour,
+        // agent.cpp:227-231).  What the sequential form does then, in one step: the first nfree new candidates in action
+        // order get the remaining slots, the others the null node.  (Hundreds of games are in this state at any time once
+        // the pools have filled: seven one-candidate calls per simulation made them the slowest waves of every launch.)
+        isnew = isnew && __popcll(need & ((1ull << lane) - 1ull)) < nfree;
+        need = __ballot(isnew);
+        cnt = __popcll(need);
+        if (lane == 0) { atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_POOL); P.gs()[TM_GS_POOL_FULL] = 1; }
     }
     int idx = found;
     {
@@ -1090,7 +1102,8 @@ __device__ __forceinline__ bool bit_test(const uint8_t* bm, uint32_t i) {
 // launches; a finished collection leaves (launch << 4) | 7 and the game's wave resumes in a LATER launch.
 // ---------------------------------------------------------------------------------------------------
 constexpr int GC_REQ = 1, GC_DONE = 7;   // phase word: (launch << 4) | GC_REQ requested, 2..5 under way (GCP_*), (launch << 4) | GC_DONE complete
-constexpr int GC_BLOCKS_MAX = 64;   // collector workgroups of a k_sim_step launch: the first half does the bounded steps, the second half the marking
+constexpr int GC_BLOCKS_MAX = 64;   // collector workgroups of a k_sim_step launch: half for the bounded steps, half for the marking (measured: with a
+                                    // quarter for the marking a collection takes 35 launches instead of 23)
 __host__ __device__ inline int gc_blocks(int n_games) {
     const int sim_blocks = (n_games + WPB - 1) / WPB;
     return sim_blocks < GC_BLOCKS_MAX ? sim_blocks : GC_BLOCKS_MAX;
@@ -1431,6 +1444,7 @@ __device__ __forceinline__ bool gc_arrive(int32_t* gs, int n_gc, bool leftover, 
     return true;
 }
 
+static_assert(3 * GC_BLOCKS_MAX <= TM_GC_PART_DW, "three counts per bounded workgroup");
 __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags, int n_gc, GcLds& M) {
     constexpr int T = 64 * WPB;
     typedef Grp<T> G_;
@@ -1523,6 +1537,9 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         const long long p0 = my_part < 0 ? 0 : my_part, p1 = my_part < 0 ? 0 : my_part + 1;      // share = [x * p0 / n_parts, x * p1 / n_parts)
         const GP P = game_ptrs(S, g);
         int32_t* gs = P.gs();
+#ifdef TM_GC_TIMING
+        const long long t_step0 = (long long)__builtin_readcyclecounter();
+#endif
         uint32_t* nmw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes);
         uint32_t* omw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes + bm_bytes);
         int32_t* queue = S.gc_queue + (size_t)g * N;
@@ -1776,6 +1793,9 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         }
         // ---- arrive; the last workgroup moves the game on ----
         __syncthreads();
+#ifdef TM_GC_TIMING   /* diagnostic build: cycles/16 part 0 spent in each step of this game's last collection -> control words 48 + step */
+        if (tid == 0 && my_part == 0) gs[48 + ph] = (ph == GCP_MARK ? gs[48 + ph] : 0) + (int)(((long long)__builtin_readcyclecounter() - t_step0) >> 4);
+#endif
         if (tid == 0) {
             bool any_left = false;
             if (gc_arrive(gs, n_gc, leftover, any_left)) {

@@ -70,7 +70,7 @@ class TreeStore:
             free_node=z(G, N), free_obs=z(G, N), gs=z(G, 64), rng=z(G, 32), env_game=z(G, 16), env_line_stats=z(G, 4),
             trace=z(G, max_trace, 4), leaf=z(G, 32), eval_obs=z(G * eval_slots),
             eval_v=z(G * eval_slots, dtype=torch.float32), eval_var=z(G * eval_slots, dtype=torch.float32),
-            gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N), gc_part=z(G, 128),
+            gc_mark=z(G, 2 * bm, dtype=torch.uint8), gc_queue=z(G, N), gc_part=z(G, 192),
             replay_obs=z(G, max(replay_cap, 1), 12), replay_stat=z(G, max(replay_cap, 1), 4, dtype=torch.float32),
             replay_count=z(G),
             mt_state=z(G if kind in (KIND_VANILLA, KIND_VANILLA_C) else 1, 625),
