@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STATE = 3803136            # conv1 82,944 + conv2 1,769,472 + conv3 1,032,192 + fc1 917,504 + fc_out 1,024
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic*.json")      # one file per profiled command line (workload_key)
 
 
 def pmc_traffic(kernels, workload_key, fetch_scale=1.0):
@@ -34,12 +34,14 @@ def pmc_traffic(kernels, workload_key, fetch_scale=1.0):
     inside this process, and the guide asks for separate passes): only used when the file was recorded with the same
     command line (its "workload_key"), otherwise the traffic is reported as null.  FETCH_SIZE + WRITE_SIZE are KiB per
     dispatch; fetch_scale = 2 for kernels whose reads are wide coalesced streams (gfx950 under-report)."""
-    path = os.path.join(ROOT, PMC_FILE)
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        doc = json.load(f)
-    if doc.get("workload_key") != workload_key:
+    import glob
+    doc = None
+    for path in sorted(glob.glob(os.path.join(ROOT, PMC_FILE))):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("workload_key") == workload_key:
+            doc = d
+    if doc is None:
         return None
     tot = 0.0
     for name in kernels:

@@ -67,7 +67,8 @@ while time.time() - t0 < args.minutes * 60:
                    best_val=(res or {}).get("best_validation"), train_s=round(time.time() - tt, 1),
                    gcs=agent.store.counter("N_GC"), gc_slices=agent.store.counter("GC_SLICES"),
                    dropped_tuples=agent.store.counter("N_DROPPED"), pool_resets=agent.store.counter("N_POOL_RESET"),
-                   catchup_launches=int((agent.store.search_stats(agent.n_sub, agent.ev_every, reset=False) or {}).get("catchup_launches", 0)),
+                   **{k: int((agent.store.search_stats(agent.n_sub, agent.ev_every, reset=False) or {}).get(k, 0))
+                      for k in ("tree_launches", "catchup_launches", "gc_launches")},
                    round_s=round(time.time() - t_round, 1))
         t_round = time.time()
         log.write(json.dumps(rec) + "\n")
