@@ -36,7 +36,8 @@ extern "C" {
 #define TM_GC_PART_DW 192   /* per-game scratch of a collection: (free nodes, free observations, harvested tuples) per collector workgroup */
 #define TM_VALUENET_PARAMS 478342
 #define TM_VALUENET_SCRATCH 9728       /* floats of scratch per state, tm_valuenet_forward_plain */
-#define TM_VALUENET_SCRATCH_MFMA 2048  /* floats of scratch per state, tm_valuenet_forward */
+#define TM_VALUENET_SCRATCH_MFMA 2064  /* floats of scratch per state, tm_valuenet_forward / _requests: ZERO-FILLED before the first call
+                                          (the kernels keep a counter per 32 states in it and leave it zero) */
 #define TM_VALUENET_PREPARED 477184    /* floats: conv2 + conv3 + fc1 operand streams */
 
 /* per-game control block (int32 words) */

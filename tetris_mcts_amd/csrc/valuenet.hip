@@ -223,10 +223,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TM_FC_KC 256   // 7 chunks (half the workgroup barriers of 128): fc1 39.2 -> 36.5 us
 #endif
 constexpr int FC_KC = TM_FC_KC, FC_PITCH = FC_KC + 4;
+// The output layer (256 -> 2, sigmoid, affine) is folded in: a tile's two workgroups (the two halves of the hidden units)
+// store their half of h with write-through (sc1) stores, wait for them, and arrive on the tile's counter; the SECOND to
+// arrive reads the other half with sc1 loads (the valid hand-off form of MI355X_MICROARCH.md: 16-byte sc1 stores and loads,
+// no fences) and runs the 2 x 256 fma chains of its 32 states - the same chain, in the same order, as k_fc_out.  Nobody
+// waits for anybody.  `cnt`: one int per tile (the first pad word of the scratch row of the tile's first state), zero before
+// the first launch (the kernel leaves it zero).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
                                                 float* __restrict__ hout, int hstride,
-                                                const int32_t* __restrict__ eval_obs) {
+                                                const int32_t* __restrict__ eval_obs, int32_t* __restrict__ cnt, int cnt_stride,
+                                                float* __restrict__ v_out, float* __restrict__ var_out) {
     __shared__ float bt[2][32 * FC_PITCH];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, l15 = lane & 15;
     const int s0 = blockIdx.x * 32;
@@ -287,17 +295,68 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
         if (c + 1 < NCH) lstore((c + 1) & 1);
         __syncthreads();
     }
-    // D[i = kk*4 + r][j = l15]: four consecutive hidden units of one state per lane -> one 16-byte store
+    // D[i = kk*4 + r][j = l15]: four consecutive hidden units of one state per lane -> one 16-byte write-through store,
+    // and a copy into LDS (hs[state][hidden unit], the layout the output layer below reads)
     const int i0 = 16 * ht + kk * 4;
-    if (s0 + l15 < n) {
-        float4 o = make_float4(acc0[0] > 0.f ? acc0[0] : 0.f, acc0[1] > 0.f ? acc0[1] : 0.f, acc0[2] > 0.f ? acc0[2] : 0.f,
-                               acc0[3] > 0.f ? acc0[3] : 0.f);
-        *reinterpret_cast<float4*>(hout + (size_t)(s0 + l15) * hstride + i0) = o;
+    float* hs = &bt[0][0];                      // 32 x HS_PITCH floats: the K loop is over, its staging buffers are free
+    constexpr int HS_PITCH = HID + 4;
+    static_assert(32 * HS_PITCH <= 2 * 32 * FC_PITCH, "hidden tile fits the staging buffers");
+    {
+        f32x4v o0, o1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o0[r] = acc0[r] > 0.f ? acc0[r] : 0.f; o1[r] = acc1[r] > 0.f ? acc1[r] : 0.f; }
+        if (s0 + l15 < n) {
+            float* dst = hout + (size_t)(s0 + l15) * hstride + i0;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(o0) : "memory");
+        }
+        if (s0 + 16 + l15 < n) {
+            float* dst = hout + (size_t)(s0 + 16 + l15) * hstride + i0;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(o1) : "memory");
+        }
+        *reinterpret_cast<f32x4v*>(&hs[l15 * HS_PITCH + i0]) = o0;
+        *reinterpret_cast<f32x4v*>(&hs[(16 + l15) * HS_PITCH + i0]) = o1;
     }
-    if (s0 + 16 + l15 < n) {
-        float4 o = make_float4(acc1[0] > 0.f ? acc1[0] : 0.f, acc1[1] > 0.f ? acc1[1] : 0.f, acc1[2] > 0.f ? acc1[2] : 0.f,
-                               acc1[3] > 0.f ? acc1[3] : 0.f);
-        *reinterpret_cast<float4*>(hout + (size_t)(s0 + 16 + l15) * hstride + i0) = o;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ int last_flag;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(&cnt[(size_t)blockIdx.x * cnt_stride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old;
+        if (old == 1) __hip_atomic_store(&cnt[(size_t)blockIdx.x * cnt_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    }
+    __syncthreads();
+    if (last_flag != 1) return;
+    // ---- this workgroup arrived second: the other half of h past the caches (32 states x 128 units = 1024 x 16 bytes) ----
+    {
+        const int ob = (1 - (int)blockIdx.y) * 128;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = it * 512 + threadIdx.x, row = e >> 5, c4 = (e & 31) * 4;
+            if (s0 + row < n) {
+                const float* src = hout + (size_t)(s0 + row) * hstride + ob + c4;
+                f32x4v w;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(src) : "memory");
+                *reinterpret_cast<f32x4v*>(&hs[row * HS_PITCH + ob + c4]) = w;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        // one chain per lane: state j = lane >> 1, output o = lane & 1 (k_fc_out's thread t = 2 s + o); fma over the 256
+        // hidden units in order
+        const int j = threadIdx.x >> 1, o = threadIdx.x & 1, sidx = s0 + j;
+        if (sidx < n && !(eval_obs && eval_obs[sidx] == 0)) {
+            float acc = P[OFF_FOB + o];
+            const float* x = &hs[j * HS_PITCH];
+            const float* wr = P + OFF_FOW + o * HID;
+#pragma unroll 8
+            for (int i = 0; i < HID; ++i) acc = fmaf(x[i], wr[i], acc);
+            const double e = tm_exp(-(double)acc);
+            const float sg = (float)(1.0 / (1.0 + e));
+            const float tt = sg * P[OFF_UB + o];
+            const float res = tt + P[OFF_LB + o];
+            if (o == 0) v_out[sidx] = res; else var_out[sidx] = res;
+        }
     }
 }
 
@@ -337,7 +396,8 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
                            const int32_t* eval_obs, int eval_slots, int max_nodes, int n, float* v, float* var,
                            float* scratch, hipStream_t stream) {
     if (n <= 0) return 0;
-    constexpr int SS = TM_VALUENET_SCRATCH_MFMA;   // a3 (1792) + hidden (256)
+    constexpr int SS = TM_VALUENET_SCRATCH_MFMA;   // a3 (1792) + hidden (256) + 16 pad words (word 0 of a tile's first row: its arrival counter)
+    static_assert(SS >= A3 + HID + 1 && SS % 4 == 0, "scratch row");
     static bool attr_set = false;
     const int lds = 4 * WAVE_LDS * (int)sizeof(float);
     if (!attr_set) {
@@ -353,8 +413,7 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, eval_obs,
                        eval_slots, max_nodes, n, scratch, SS);
     hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(512), 0, stream, P, prepared, scratch, SS, n,
-                       scratch + A3, SS, eval_obs);
-    hipLaunchKernelGGL(k_fc_out, dim3((n * 2 + 255) / 256), dim3(256), 0, stream, scratch + A3, SS, P, v, var, n, eval_obs);
+                       scratch + A3, SS, eval_obs, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
     return (int)hipGetLastError();
 }
 

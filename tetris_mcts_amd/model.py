@@ -18,6 +18,7 @@ import torch.nn as nn
 from . import _lib
 from .store import _p, _stream
 
+SCRATCH_MFMA = 2064     # TM_VALUENET_SCRATCH_MFMA (include/tetris_mcts_hip.h): floats of scratch per state, zero-filled once
 PARAM_ORDER = ["head.conv1.weight", "head.conv1.bias", "head.conv2.weight", "head.conv2.bias", "head.conv3.weight",
                "head.conv3.bias", "head.fc1.weight", "head.fc1.bias", "head.fc_out.weight", "head.fc_out.bias",
                "out_ubound", "out_lbound"]
@@ -143,8 +144,8 @@ class Model_VV:
             v_out = torch.empty(B, dtype=torch.float32, device=self.device)
             var_out = torch.empty(B, dtype=torch.float32, device=self.device)
         if self.backend == "hip":
-            if self._scratch is None or self._scratch.shape[0] < B:
-                self._scratch = torch.empty(B, 2048, dtype=torch.float32, device=self.device)
+            if self._scratch is None or self._scratch.shape[0] < B or self._scratch.shape[1] < SCRATCH_MFMA:
+                self._scratch = torch.zeros(B, SCRATCH_MFMA, dtype=torch.float32, device=self.device)
             P = self.flat_params()
             if self._prepared is None:
                 self._prepared = torch.empty(477184, dtype=torch.float32, device=self.device)
@@ -165,8 +166,8 @@ class Model_VV:
     @torch.no_grad()
     def hip_buffers(self, n_states):
         """(params, prepared operand streams, scratch for n_states) as ctypes pointers for the C ABI (search.hip)."""
-        if self._scratch is None or self._scratch.shape[0] < n_states or self._scratch.shape[1] < 2048:
-            self._scratch = torch.empty(n_states, 2048, dtype=torch.float32, device=self.device)
+        if self._scratch is None or self._scratch.shape[0] < n_states or self._scratch.shape[1] < SCRATCH_MFMA:
+            self._scratch = torch.zeros(n_states, SCRATCH_MFMA, dtype=torch.float32, device=self.device)
         P = self.flat_params()
         if self._prepared is None:
             self._prepared = torch.empty(477184, dtype=torch.float32, device=self.device)
@@ -178,8 +179,8 @@ class Model_VV:
         """Evaluate a TreeStore's pending leaf requests in place (fused render + forward, HIP back end only)."""
         import ctypes as C
         B = store.n_games * store.eval_slots
-        if self._scratch is None or self._scratch.shape[0] < B or self._scratch.shape[1] < 2048:
-            self._scratch = torch.empty(B, 2048, dtype=torch.float32, device=self.device)
+        if self._scratch is None or self._scratch.shape[0] < B or self._scratch.shape[1] < SCRATCH_MFMA:
+            self._scratch = torch.zeros(B, SCRATCH_MFMA, dtype=torch.float32, device=self.device)
         P = self.flat_params()
         if self._prepared is None:
             self._prepared = torch.empty(477184, dtype=torch.float32, device=self.device)
