@@ -312,10 +312,10 @@ def main():
                  "sampled intervals %.4f / %.4f ms, each carrying its own event records); avg_launch_ms x %d simulations <= "
                  "ms_per_step by construction.  The rocprofv3 kernel trace of the same command is profiles/r03_kernel_stats_*.csv"
                  % (kf["per_sim_ms"], EV_EVERY, kf["nn_event_ms"], kf["tree_event_ms"], sims))
-        nn_roof = {"kernel": "value net forward (k_vn_conv + k_vn_fc1 + k_fc_out), per launch of %d request slots" % int(Gs * K),
+        nn_roof = {"kernel": "value net forward (k_vn_conv + k_vn_fc1 with the output layer folded in), per launch of %d request slots" % int(Gs * K),
                    "bound": "mfma", "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                    "frac": a_tf / PEAK_F32_MATRIX_TFLOPS,
-                   "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1", "tmcts_vn::k_fc_out"], workload_key, 2.0)
+                   "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1"], workload_key, 2.0)
                    if args.backend == "hip" else None,
                    "traffic_note": note + "; FETCH_SIZE x2 (wide streams)",
                    "avg_launch_ms": nn_ms, "launches_timed": kf["timed"], "events_every": EV_EVERY, "timing_note": tnote}
