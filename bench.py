@@ -52,6 +52,16 @@ def pmc_traffic(kernels, workload_key, fetch_scale=1.0):
     return tot
 
 
+FLOP_PER_STATE_DIST = 2770432       # model_distributional.Net on 22x10: conv1 136,192 + conv2 2,097,152 + fc1 524,288 + fc_v 12,800
+
+
+def bytes_per_sim_dist(mean_trace_len):
+    """Algorithmic bytes per simulation of the distributional agent: per level 128 B record + 7 x 16 B
+    child statistics (select), 16 B trace entry + 2 x 16 B statistics + 2 x 200 B distribution (backup); expansion and leaf
+    gather as SURVEY.md 8(d) (1296 B; 200 B observation read + 880 B network input written)."""
+    return (240.0 + 448.0) * mean_trace_len + 1296.0 + 1080.0
+
+
 def bytes_per_sim(mean_trace_len, k_eval):
     """SURVEY.md 8(d) algorithmic bytes per simulation (packed game 64 B, packed observation 64 B, U = 7)."""
     return 204.0 * mean_trace_len - 144.0 + 1296.0 + 1000.0 * k_eval
@@ -65,7 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--games", type=int, default=4096, help="games per GPU")
     ap.add_argument("--sims", type=int, default=500)
-    ap.add_argument("--agent", default="ValueSim", choices=["ValueSim", "ValueSimLP"])
+    ap.add_argument("--agent", default="ValueSim", choices=["ValueSim", "ValueSimLP", "DistValueSim"])
     ap.add_argument("--max-nodes", type=int, default=100000)
     ap.add_argument("--backend", default="hip", choices=["hip", "torch"])
     ap.add_argument("--split", type=int, default=int(os.environ.get("TM_BENCH_SPLIT", "1")),
@@ -108,7 +118,14 @@ def main():
     G, sims, NS = args.games, args.sims, args.split
     EV_EVERY = int(os.environ.get("TM_BENCH_EVENT_EVERY", "16"))
     env_args = ((20, 10), 1, 0, 0)
-    model = Model_VV(backend=args.backend, seed=0)  # model_vv.Net() under torch.manual_seed(0) (random init)
+    is_dist = args.agent == "DistValueSim"
+    if is_dist:
+        # BASELINE configs[4]: the distributional head (model/model_distributional.py Net, 50 atoms over [0, 5000)), random init
+        from tetris_mcts_amd.model_distributional import Model_Dist
+        model = Model_Dist(atoms=50, seed=0)
+        assert not args.online, "the distributional agent has no online leg (DESIGN.md section 8)"
+    else:
+        model = Model_VV(backend=args.backend, seed=0)  # model_vv.Net() under torch.manual_seed(0) (random init)
     game = Tetris(*env_args, seed=tdist.game_seeds(20260925, G, rank), n_games=G)     # game g of rank r = game r*G + g of the job
     okw = dict(online=True, min_visits_to_store=10, replay_cap=16384) if args.online else dict(online=False)
     agent = getattr(agents, args.agent)(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=args.max_nodes,
@@ -166,6 +183,8 @@ def main():
         episodes, lines = 0, 0
         torch.cuda.synchronize()
         S.search_stats(NS, EV_EVERY, reset=True)
+        if is_dist:
+            agent.loop_stats(reset=True)
         if world > 1:
             dist.barrier()
         c0 = counters()
@@ -179,6 +198,8 @@ def main():
         elapsed = time.perf_counter() - t0
         c1 = counters()
         ss = S.search_stats(NS, EV_EVERY, reset=False) or {}
+        if is_dist:      # the launch loop ran in Python (TreeAgent.mcts): its own sampled events
+            ss = agent.loop_stats(reset=True)
         err = int((S.errors() != 0).sum().item())
         d = {k: c1[k] - c0[k] for k in c0}
         tot = torch.tensor([elapsed, d["N_EXPAND"], d["N_SIMS"], d["TRACE_SUM"], d["N_EVAL"], episodes, lines, err,
@@ -201,6 +222,10 @@ def main():
         time per simulation the two must add up to (the sampled intervals each carry the cost of their own event records,
         so their plain sum slightly exceeds the step)."""
         ss = r["ss"]
+        if is_dist and ss.get("timed"):      # Python-driven loop: the sampled intervals as they are
+            nn_ev, tree_ev = ss["nn_ms_sum"] / ss["timed"], ss["tree_ms_sum"] / ss["timed"]
+            return dict(nn_ms=nn_ev, tree_ms=tree_ev, nn_event_ms=nn_ev, tree_event_ms=tree_ev, per_sim_ms=nn_ev + tree_ev,
+                        timed=int(ss["timed"]))
         if not ss.get("timed") or not ss.get("loop_sims"):
             return None
         nn_ev, tree_ev = ss["nn_ms_sum"] / ss["timed"], ss["tree_ms_sum"] / ss["timed"]
@@ -231,7 +256,7 @@ def main():
         return
     elapsed, n_exp, n_sims, n_eval = head["elapsed"], head["n_exp"], head["n_sims"], head["n_eval"]
     mean_len = head["tr_sum"] / max(n_sims, 1.0)
-    cfg_idx = 1 if args.agent == "ValueSim" else 2
+    cfg_idx = {"ValueSim": 1, "ValueSimLP": 2, "DistValueSim": 4}[args.agent]
     workload_key = "%s G=%d sims=%d pool=%d warmup=%d steps=%d split=%d" % (args.agent, G, sims, args.max_nodes,
                                                                            args.warmup, args.steps, NS)
 
@@ -301,9 +326,9 @@ def main():
         nn_ms, tree_ms = kf["nn_ms"], kf["tree_ms"]
         Gs = G / NS
         evals_per_launch = n_eval / max(n_sims, 1.0) * Gs
-        flops = FLOP_PER_STATE * evals_per_launch
+        flops = (FLOP_PER_STATE_DIST if is_dist else FLOP_PER_STATE) * evals_per_launch
         a_tf = flops / (nn_ms * 1e-3) / 1e12
-        bps = bytes_per_sim(mean_len, 1 if args.agent == "ValueSim" else n_eval / max(n_exp, 1.0))
+        bps = bytes_per_sim_dist(mean_len) if is_dist else bytes_per_sim(mean_len, 1 if args.agent == "ValueSim" else n_eval / max(n_exp, 1.0))
         a_gbs = bps * Gs / (tree_ms * 1e-3) / 1e9
         note = ("bytes/launch from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line); null when "
                 "that file was recorded for another workload" % PMC_FILE)
@@ -312,11 +337,11 @@ def main():
                  "sampled intervals %.4f / %.4f ms, each carrying its own event records); avg_launch_ms x %d simulations <= "
                  "ms_per_step by construction.  The rocprofv3 kernel trace of the same command is profiles/r03_kernel_stats_*.csv"
                  % (kf["per_sim_ms"], EV_EVERY, kf["nn_event_ms"], kf["tree_event_ms"], sims))
-        nn_roof = {"kernel": "value net forward (k_vn_conv + k_vn_fc1 with the output layer folded in), per launch of %d request slots" % int(Gs * K),
+        nn_roof = {"kernel": ("distributional head (model_distributional.Net on PyTorch-ROCm: MIOpen / rocBLAS kernels + the request render), per evaluation of %d leaves" if is_dist else "value net forward (k_vn_conv + k_vn_fc1 with the output layer folded in), per launch of %d request slots") % int(Gs * K),
                    "bound": "mfma", "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                    "frac": a_tf / PEAK_F32_MATRIX_TFLOPS,
                    "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1"], workload_key, 2.0)
-                   if args.backend == "hip" else None,
+                   if (args.backend == "hip" and not is_dist) else None,
                    "traffic_note": note + "; FETCH_SIZE x2 (wide streams)",
                    "avg_launch_ms": nn_ms, "launches_timed": kf["timed"], "events_every": EV_EVERY, "timing_note": tnote}
         tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % int(Gs), "bound": "hbm",
@@ -328,7 +353,10 @@ def main():
         out["roofline"] = nn_roof if nn_ms >= tree_ms else tree_roof
         out["roofline_other"] = tree_roof if nn_ms >= tree_ms else nn_roof
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, model)
+        out["cpu_baseline"] = ({"value": None, "unit": "node-expansions/s", "cores": 0, "kind": "port",
+                                "sample": "none: the reference has no distributional agent that runs (agents/DistValueSimOnline.py does "
+                                          "not import); the oracle's restatement is a checker, timed nowhere"}
+                               if is_dist else cpu_baseline(args, model))
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -33,6 +33,7 @@ extern "C" {
 #define TM_KIDS_DW 8       /* raw children row: child[7] in action order + pad */
 #define TM_GS_DW 64        /* per-game control block */
 #define TM_LEAF_DW 32      /* per-game leaf hand-off between the front and back halves of a simulation */
+#define TM_DIST_ROW 64       /* floats per row of node_dist / eval_dist (dist_bins <= 64 atoms, zero padded) */
 #define TM_GC_PART_DW 192   /* per-game scratch of a collection: (free nodes, free observations, harvested tuples) per collector workgroup */
 #define TM_VALUENET_PARAMS 478342
 #define TM_VALUENET_SCRATCH 9728       /* floats of scratch per state, tm_valuenet_forward_plain */
@@ -85,6 +86,10 @@ enum {
 #define TM_KIND_VANILLA 4      /* agents/Vanilla.py:42-64       : random rollout to the end of the game (CPython MT19937 randint), variance 1e3 */
 #define TM_KIND_VANILLA_C 5    /* agents/VanillaC.py:5-14 via agent.cpp:447-455 (evaluator type 1): rollout with randint(0, 7),
                                   variance 1e5, float carry, the C++ agent's root statistics */
+#define TM_KIND_DIST 6         /* DistValueSim: the reference's unfinished distributional agent (agents/DistValueSimOnline.py, does
+                                  not import) rebuilt from its working parts - agents/core_distributional.py:12-124 - on a tree without
+                                  the observation projection: obs_stat[node] = (visit, mean, variance, M2) as floats, node_dist[node] =
+                                  dist_bins atoms over [dist_vmin, dist_vmax); the evaluator fills eval_dist; low = 5 */
 
 typedef struct tm_store {
     /* sizes */
@@ -133,6 +138,12 @@ typedef struct tm_store {
     uint32_t *mt_state;   /* [G][625] CPython random state per game (624 words + index), TM_KIND_VANILLA / TM_KIND_VANILLA_C rollouts (Vanilla.py:4,52) */
     uint32_t *node_child; /* [G][N][8] raw child[7] per action (agents/agent.py:61) + pad */
     int32_t *gc_part;     /* [G][TM_GC_PART_DW] per-collector counts of a collection in progress */
+    /* TM_KIND_DIST only */
+    float *node_dist;     /* [G][N][TM_DIST_ROW] the nodes' value distributions (agents/core_distributional.py node_dist) */
+    float *eval_dist;     /* [G][TM_DIST_ROW] the evaluator's distribution for the game's pending leaf (model_distributional.Net) */
+    const double *nq_table_d; /* [nq_size] norm_quantile(n) in double (policy_dist multiplies in double), host libm */
+    double dist_vmin, dist_vmax;
+    int32_t dist_bins, reserved_;
 } tm_store;
 
 /* pools, free lists, tables, rng (seed 1), control blocks.  Everything else must be zero-filled by the caller. */
@@ -142,6 +153,7 @@ int tm_pool_init(const tm_store *s, void *stream);
 int tm_pool_reset(const tm_store *s, const uint8_t *mask, void *stream);
 /* host helper: fills host_table[n] = (float)norm_quantile((double)i) with this machine's libm */
 void tm_fill_norm_quantile(float *host_table, int n);
+void tm_fill_norm_quantile_f64(double *host_table, int n);      /* the same values in double (TM_KIND_DIST: nq_table_d) */
 
 /* environment (batched pyTetris) */
 int tm_env_init(const tm_store *s, const uint32_t *seeds, void *stream);                /* Tetris(...) */

@@ -18,6 +18,7 @@ OBS_DTYPE = np.dtype([("rows", "<u2", (20,)), ("cells", "u1", (4,)), ("end", "u1
 assert GAME_DTYPE.itemsize == 64 and OBS_DTYPE.itemsize == 48
 
 EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+DIST_EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
 
 
 def build(ref=True):
@@ -88,6 +89,10 @@ def lib():
         L.orc_get_all_childs.argtypes = [i32, vp, i32, vp]
         L.orc_valuenet_forward.argtypes = [vp, vp, i32, vp, vp]
         L.orc_hash_eval.argtypes = [vp, vp, i32, vp, vp]
+        L.orc_hash_dist.argtypes = [vp, vp, i32, i32, vp]
+        L.orc_agent_set_dist.argtypes = [vp, i32, f64, f64, vp]
+        L.orc_agent_node_stats.restype = L.orc_agent_node_dist.restype = vp
+        L.orc_agent_node_stats.argtypes = L.orc_agent_node_dist.argtypes = [vp]
         L.orc_transform_distribution.argtypes = [vp, i32, f64, f64, f64, f64, vp]
         L.orc_mean_dist.restype, L.orc_mean_dist.argtypes = f64, [vp, i32, f64, f64]
         L.orc_mean_variance_dist.argtypes = [vp, i32, f64, f64, vp]
@@ -149,13 +154,13 @@ class Agent:
 
     def __init__(self, kind, max_nodes=100000, app=1, scoring=0, randomizer=0, gamma=0.999, low=1, benchmark=False,
                  online=False, min_visits_to_store=None, memory_size=0, evaluator="hash", params=None,
-                 cpp_occupied=False):
+                 cpp_occupied=False, dist_bins=50, dist_vmin=0.0, dist_vmax=5000.0):
         L = lib()
         self.L = L
         if min_visits_to_store is None:
             min_visits_to_store = {0: 10, 1: 25}.get(kind, 40)
         self._keep = None
-        if evaluator == "hash":
+        if evaluator == "hash" or kind == 6:
             fn, ctx = C.cast(L.orc_hash_eval, C.c_void_p), None
         elif evaluator == "valuenet":
             self._keep = np.ascontiguousarray(params, np.float32)
@@ -172,6 +177,20 @@ class Agent:
         self.max_nodes = max_nodes
         self.h = L.orc_agent_new(max_nodes, app, scoring, randomizer, kind, gamma, low, int(benchmark), int(online),
                                  min_visits_to_store, memory_size, fn, ctx)
+        if kind == 6:
+            # DistValueSim (agent_oracle.c kind 6): per-node statistics and distributions; evaluator "hash" = orc_hash_dist, or a
+            # python callable(states int8 [k,20,10]) -> float32 [k, bins]
+            self.bins, self.vrange = int(dist_bins), (float(dist_vmin), float(dist_vmax))
+            if evaluator == "hash":
+                dfn = C.cast(L.orc_hash_dist, C.c_void_p)
+            else:
+                def _dcb(_ctx, states, k, bins, out):
+                    st = np.ctypeslib.as_array(C.cast(states, C.POINTER(C.c_int8)), (k, 20, 10))
+                    d = np.asarray(evaluator(st.copy()), np.float32).reshape(k, bins)
+                    np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_float)), (k, bins))[:] = d
+                self._keep_dist = DIST_EVAL_FN(_dcb)
+                dfn = C.cast(self._keep_dist, C.c_void_p)
+            L.orc_agent_set_dist(self.h, self.bins, self.vrange[0], self.vrange[1], dfn)
         if cpp_occupied:
             # the reference C++ agent's `occupied` vector slip (agent.cpp:300-301, see agent_oracle.c); only where the
             # oracle is compared with the reference's compiled agent, never where it checks the product
@@ -221,6 +240,11 @@ class Agent:
 
     def stats(self):
         return self._arr("stats", np.float32, (3, 7)).copy()
+
+    def dist_arrays(self):
+        """kind 6: (node_stats [n,5] = visit, mean, score, variance, M2; node_dist [n,bins]) as core_distributional.py holds them"""
+        n = self.max_nodes
+        return self._arr("node_stats", np.float32, (n, 5)), self._arr("node_dist", np.float32, (n, self.bins))
 
     def memory(self):
         m = self.L.orc_agent_memory_index(self.h)

@@ -30,12 +30,12 @@ def test_every_declared_symbol_is_exported():
 
 def test_store_layout_matches_ctypes_mirror():
     L = _lib()
-    out = (C.c_int * 9)()
-    n = L.lib().tm_store_layout(out, 9)
+    out = (C.c_int * 10)()
+    n = L.lib().tm_store_layout(out, 10)
     T = L.TmStore
-    assert n == 9 and list(out)[:n] == [C.sizeof(T), T.gamma.offset, T.node_rec.offset, T.nq_table.offset,
-                                        T.replay_count.offset, T.mt_state.offset, T.node_child.offset,
-                                        T.gc_slice_cycles.offset, T.gc_part.offset]
+    assert n == 10 and list(out)[:n] == [C.sizeof(T), T.gamma.offset, T.node_rec.offset, T.nq_table.offset,
+                                         T.replay_count.offset, T.mt_state.offset, T.node_child.offset,
+                                         T.gc_slice_cycles.offset, T.gc_part.offset, T.dist_vmin.offset]
 
 
 def test_norm_quantile_table_is_the_reference_formula(oracle):

@@ -105,3 +105,34 @@ def test_distpy_backup_matches_the_reference_function(oracle, golden_dir):
         assert ns[untouched].tobytes() == c["stats_in"][untouched].tobytes()
         n += 1
     assert n == 12
+
+
+def test_oracle_dist_agent_invariants(oracle):
+    """The oracle's DistValueSim (agent_oracle.c kind 6: TreeAgent's tree + the kernels above, which are pinned on the
+    reference functions): visits add up, every visited node's distribution is normalised and its mean statistic is the
+    running mean the backup defines; collections happen and keep the statistics of what stays reachable."""
+    g = oracle.Game(seed=11)
+    a = oracle.Agent(6, max_nodes=4000, low=5)
+    a.update_root(g)
+    sims = 120
+    for m in range(14):
+        act = a.play(sims)
+        st = a.stats()
+        assert 0 <= act < 7 and np.isfinite(st).all()
+        assert act == int(np.argmax(st[1]))
+        g.play(act)
+        a.update_root(g)
+    assert a.error == 0 and a.n_sims == 14 * sims and a.n_gc >= 1
+    ns, nd = a.dist_arrays()
+    arr = a.arrays()
+    mark = np.zeros(4000, np.uint8)
+    oracle.lib().orc_get_all_childs(a.root, oracle.ptr(arr["child"]), 4000, oracle.ptr(mark))
+    occ = np.nonzero(mark)[0]
+    occ = occ[occ != 0]
+    vis = ns[occ, 0]
+    assert (vis >= 0).all() and np.all(vis == np.round(vis))
+    seen = occ[vis > 0]
+    assert len(seen) > 50
+    assert np.allclose(nd[seen].sum(1), 1.0, atol=2e-5)
+    assert np.all(ns[occ, 2] == arr["score"][occ])            # node_stats[:, 2] is the node's score
+    assert np.all(ns[seen, 3] >= 0)

@@ -22,6 +22,8 @@ class TmStore(C.Structure):
         ("free_node", vp), ("free_obs", vp), ("gs", vp), ("rng", vp), ("env_game", vp), ("env_line_stats", vp),
         ("trace", vp), ("leaf", vp), ("eval_obs", vp), ("eval_v", vp), ("eval_var", vp), ("nq_table", vp),
         ("gc_mark", vp), ("gc_queue", vp), ("replay_obs", vp), ("replay_stat", vp), ("replay_count", vp), ("mt_state", vp), ("node_child", vp), ("gc_part", vp),
+        ("node_dist", vp), ("eval_dist", vp), ("nq_table_d", vp), ("dist_vmin", f64), ("dist_vmax", f64), ("dist_bins", i32),
+        ("reserved_", i32),
     ]
 
 
@@ -83,6 +85,7 @@ def lib():
             f = getattr(L, name)
             f.argtypes, f.restype = args, i32
         L.tm_fill_norm_quantile.argtypes, L.tm_fill_norm_quantile.restype = [vp, i32], None
+        L.tm_fill_norm_quantile_f64.argtypes, L.tm_fill_norm_quantile_f64.restype = [vp, i32], None
         L.tm_version.argtypes, L.tm_version.restype = [], C.c_char_p
         L.tm_store_layout.argtypes, L.tm_store_layout.restype = [vp, i32], i32
         L.tm_search_destroy.argtypes, L.tm_search_destroy.restype = [vp], None

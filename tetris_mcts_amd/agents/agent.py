@@ -55,6 +55,7 @@ class TreeAgent(Agent):
                                   min_visits_to_store=min_visits_to_store, replay_cap=replay_cap, max_trace=max_trace,
                                   nq_size=nq_size, gc_slice_cycles=gc_slice_cycles)
         self.n_sub, self.ev_every = int(n_sub), int(ev_every)
+        self._pending_events, self.loop_events, self.catchup_launches = [], dict(timed=0, nn_ms_sum=0.0, tree_ms_sum=0.0), 0
         self.store = None
         self.reset_on_pool_exhaustion = reset_on_pool_exhaustion
         self._pending_pool_reset = None
@@ -95,16 +96,47 @@ class TreeAgent(Agent):
         both = st.SIM_BACKUP | st.SIM_FRONT
         s.move_begin(sims)
         s.sim_step(both)
-        todo = sims
+        todo, first = sims, True
+        ev = self.ev_every if first else 0
         while todo > 0:
-            for _ in range(todo):
-                self.evaluate_requests()
-                s.sim_step(both)
+            for i in range(todo):
+                if first and ev and i % ev == 0:
+                    # events around the evaluator and the tree kernel of every ev-th simulation (the Python-driven loop's
+                    # counterpart of tm_search_stats; summed in self.loop_events and read by the benchmark)
+                    import torch
+                    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    e[0].record()
+                    self.evaluate_requests()
+                    e[1].record()
+                    s.sim_step(both)
+                    e[2].record()
+                    self._pending_events.append(e)
+                else:
+                    self.evaluate_requests()
+                    s.sim_step(both)
+            if not first:
+                self.catchup_launches += todo
+            first = False
             todo, collecting = s.sims_remaining()
             while collecting:                      # catch-up: collections under way are finished by collector-only launches
                 for _ in range(6):
                     s.gc_step()
                 todo, collecting = s.sims_remaining()
+
+    def loop_stats(self, reset=True):
+        """Python-driven loop only: dict(timed, nn_ms_sum, tree_ms_sum, catchup_launches) from the sampled event triples"""
+        import torch
+        torch.cuda.synchronize()
+        for e in self._pending_events:
+            self.loop_events["nn_ms_sum"] += e[0].elapsed_time(e[1])
+            self.loop_events["tree_ms_sum"] += e[1].elapsed_time(e[2])
+            self.loop_events["timed"] += 1
+        self._pending_events = []
+        out = dict(self.loop_events, catchup_launches=self.catchup_launches)
+        if reset:
+            self.loop_events = dict(timed=0, nn_ms_sum=0.0, tree_ms_sum=0.0)
+            self.catchup_launches = 0
+        return out
 
     def play(self):
         self.mcts(self.sims)

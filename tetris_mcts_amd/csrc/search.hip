@@ -73,6 +73,7 @@ int tm_store_slice(const tm_store* s, int first, int n, tm_store* out) {
     t.gc_mark += f * 2 * bm_bytes;
     t.gc_queue += f * N;
     t.gc_part += f * TM_GC_PART_DW;
+    if (s->kind == TM_KIND_DIST) { t.node_dist += f * N * TM_DIST_ROW; t.eval_dist += f * TM_DIST_ROW; }
     if (t.replay_obs) t.replay_obs += f * (size_t)s->replay_cap * TM_OBS_DW;
     if (t.replay_stat) t.replay_stat += f * (size_t)s->replay_cap * 4;
     if (t.replay_count) t.replay_count += f;

@@ -332,9 +332,10 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     }
     table_insert_seq(P.ntab(), mask, need, n, lane, h, ins, idx, L.misc);
     // 3. observations of the new nodes (agents/agent.py:112-128)
+    const bool ident = S.kind == TM_KIND_DIST;      // no projection: a node's statistics are its own (observation index = node index)
     uint32_t* ok = L.okeys[act ? lane : 0];
     uint64_t ho = 0;
-    if (isnew) { pack_obs(my, ok); ho = hash_obs(ok); }
+    if (isnew && !ident) { pack_obs(my, ok); ho = hash_obs(ok); }
     wave_sync();
     int odup = lane;
     for (int b = 0; b < n; ++b) {
@@ -342,7 +343,7 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         bool bnew = (need >> b) & 1ull;
         if (isnew && bnew && odup == lane && b < lane && hb == ho && eq_lds(ok, L.okeys[b], OBS_DW)) odup = b;
     }
-    const bool ouniq = isnew && odup == lane;
+    const bool ouniq = isnew && odup == lane && !ident;
     int ofound = 0;
     uint32_t oins = 0;
     bool ofull = false;
@@ -376,6 +377,14 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     {   // same observation as an earlier new candidate
         int osrc = shfl_u32((uint32_t)o, odup);
         if (isnew && odup != lane) o = osrc;
+    }
+    if (ident && isnew) {
+        // node_stats = (visit, mean, variance, M2) as floats, all zero; node_dist row zero (core_distributional.py's arrays)
+        o = idx;
+        *reinterpret_cast<uint4*>(P.stat() + (size_t)idx * 4) = make_uint4(0u, 0u, 0u, 0u);
+        uint4* dr = reinterpret_cast<uint4*>(S.node_dist + ((size_t)g * P.n() + (size_t)idx) * TM_DIST_ROW);
+#pragma unroll
+        for (int t = 0; t < TM_DIST_ROW / 4; ++t) dr[t] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (isnew) {
         uint4* dst = reinterpret_cast<uint4*>(P.game() + (size_t)idx * GAME_DW);
@@ -738,8 +747,8 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
         if (VANILLA) {
             k_eval = 0;
             if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
-        } else if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT) {
-            k_eval = 1;
+        } else if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT || kind == TM_KIND_DIST) {
+            k_eval = 1;      // (TM_KIND_DIST: the request names the leaf NODE - identity projection)
             if (lane == 0) P.eval_obs()[0] = (int)self_o;
         } else {
             // unique children of the freshly expanded leaf (ValueSimLP.py:55 / agent.cpp:424)
@@ -1085,6 +1094,183 @@ __device__ __forceinline__ bool bit_test(const uint8_t* bm, uint32_t i) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// DistValueSim (TM_KIND_DIST): the reference's unfinished distributional agent rebuilt from its working parts
+// (agents/DistValueSimOnline.py:12-94 does not import; agents/core_distributional.py:12-124 holds the kernels).
+// Tree without the observation projection: obs_stat[node] = (visit, mean, variance, M2) as floats (node_stats of
+// core_distributional.py; the score is in the record), node_dist[node] = `bins` atoms over [vmin, vmax).  The numerics are
+// those of the oracle's restatement (oracle/dist_oracle.c orc_distpy_policy / orc_distpy_backup, pinned on a pure-Python
+// run of the reference functions): float32 arrays, float64 scalars, an element op a float64 scalar done in double and
+// rounded on the store.
+// ---------------------------------------------------------------------------------------------------
+// backup_trace_distributional (core_distributional.py:108-124): every node of the trace gets the leaf's distribution
+// shifted by the reward between it and the leaf (shift_distribution :12-37) averaged into its own, and a Welford update of
+// its mean / M2 / variance.  One lane per atom; a destination bin gathers its (at most a handful of) source bins in
+// ascending order, which is the order the reference's scatter loop adds them in.
+__device__ __forceinline__ void wave_dist_back(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int gsv) {
+    const int len = GSV(gsv, TM_GS_TRACE_LEN);
+    const int leaf_end = GSV(gsv, TM_GS_LEAF_END);
+    const int bins = S.dist_bins;
+    const double vmin = S.dist_vmin, vmax = S.dist_vmax;
+    const double delta = (vmax - vmin) / bins;
+    const double r = (double)GSV(gsv, TM_GS_LEAF_SCORE);               // value = leaf_game.getScore()
+    float* dl = reinterpret_cast<float*>(L.slots);                     // the leaf's distribution, in LDS for the gathers
+    // v_dummy (all mass in bin 0) for a finished game, else the evaluator's output (DistValueSimOnline.py:25-26,66-74)
+    const float d_own = lane < bins ? (leaf_end ? (lane == 0 ? 1.0f : 0.0f) : S.eval_dist[(size_t)g * TM_DIST_ROW + lane]) : 0.0f;
+    dl[lane] = d_own;
+    wave_sync();
+    double mean = 0;                                                   // mean_dist (:40-46), bins in ascending order
+    for (int b = 0; b < bins; ++b) mean = mean + (double)dl[b] * (((double)b + 0.5) * delta);
+    float* nd_base = S.node_dist + (size_t)g * P.n() * TM_DIST_ROW;
+    for (int i = 0; i < len; ++i) {
+        const uint4 e = reinterpret_cast<const uint4*>(P.trace())[i];   // (node, node, score bits, header)
+        const int idx = (int)e.x;
+        uint32_t* st = P.stat() + (size_t)idx * 4;
+        const uint4 sv = *reinterpret_cast<const uint4*>(st);
+        float* nd = nd_base + (size_t)idx * TM_DIST_ROW;
+        const float nd_old = lane < bins ? nd[lane] : 0.0f;
+        const float n0 = __uint_as_float(sv.x), m_old = __uint_as_float(sv.y), var_old = __uint_as_float(sv.z), m2_old = __uint_as_float(sv.w);
+        const double _r = r - (double)__uint_as_float(e.z);
+        const double bin_shift = _r / delta;
+        const double fraction = bin_shift - floor(bin_shift);
+        // shift_distribution as a gather: the sources of destination bin j are the b with lo(b) == j (weight 1 - fraction)
+        // or hi(b) == j (weight fraction), lo(b) = min(int(b + bin_shift), bins - 1), hi(b) = min(lo + 1, bins - 1); for
+        // j < bins - 1 they lie in [j - s - 2, j - s + 1] (s = int(bin_shift); the slack covers the rounding of b +
+        // bin_shift), for the top bin in [bins - 1 - s - 2, bins - 1]
+        float acc = 0.0f;
+        if (lane < bins) {
+            const int sft = (int)bin_shift;
+            const int b_first = max(0, lane - sft - 2), b_last = lane == bins - 1 ? bins - 1 : min(bins - 1, lane - sft + 1);
+            for (int b = b_first; b <= b_last; ++b) {
+                int lo = (int)((double)b + bin_shift);
+                if (lo >= bins) lo = bins - 1;
+                const int hi = (lo + 1 >= bins) ? bins - 1 : lo + 1;
+                // (negative indices - a node scoring more than the leaf - do not occur: the score never decreases along a game)
+                if (lo == lane) acc = (float)((double)acc + (double)dl[b] * (1 - fraction));
+                if (hi == lane) acc = (float)((double)acc + (double)dl[b] * fraction);
+            }
+            const float m = nd_old * n0;
+            const float u = m + acc;
+            nd[lane] = (float)((double)u / ((double)n0 + 1.0));
+        }
+        if (lane == 0) {
+            const double x = mean + _r;
+            const float n1 = n0 + 1.0f;
+            const double d1 = x - (double)m_old;
+            const float v = (float)((double)m_old + d1 / (double)n1);
+            const double d2 = x - (double)v;
+            const float m2 = (float)((double)m2_old + d1 * d2);
+            const float var = n1 > 1.0f ? (float)((double)m2 / ((double)n1 - 1.0)) : var_old;
+            *reinterpret_cast<uint4*>(st) = make_uint4(__float_as_uint(n1), __float_as_uint(v), __float_as_uint(var), __float_as_uint(m2));
+        }
+    }
+    wave_sync();
+    if (lane == 0) { P.gs()[TM_GS_PENDING] = 0; P.gs()[TM_GS_N_SIMS] = GSV(gsv, TM_GS_N_SIMS) + 1; }
+}
+
+// select_trace_distributional (core_distributional.py:81-104): under-visited children first (check_low, libc rand()),
+// else policy_dist (:66-79): q = (mean + score - own score) + norm_quantile(n) * sqrt(variance / (visit + 1e-3)), first
+// argmax (np.argmax: the first NaN wins).  One 8-lane group per unique child (the record's pieces), one dependent pair of
+// loads per level (record -> children's statistics).
+template <bool VANILLA>
+__device__ __forceinline__ void wave_dist_front(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int gsv, int gc_req_word) {
+    const long long tc_start = __builtin_readcyclecounter();
+    if (lane < 32) L.misc[lane] = S.rng[(size_t)g * 32 + lane];
+    wave_sync();
+    int rng_pos = GSV(gsv, TM_GS_RNG_POS);
+    const int rng_pos0 = rng_pos;
+    int idx = GSV(gsv, TM_GS_ROOT);
+    int len = 0, flushed = 0;
+    bool overflow = false;
+    const int grp = lane >> 3;
+    const uint32_t grp16 = (uint32_t)grp * 16u;
+    const __amdgpu_buffer_rsrc_t rec_rs = make_rsrc(P.rec(), P.n() * (TM_REC_DW * 4u));
+    const __amdgpu_buffer_rsrc_t stat_rs = make_rsrc(P.stat(), P.n() * 16u);
+    const float lowf = (float)S.low;
+    const double* nqd = S.nq_table_d;
+    int nq_fallback = 0;
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    for (;;) {
+        const uint4 rc = buf_ld16(rec_rs, (uint32_t)idx * (TM_REC_DW * 4u) + grp16);       // group j: piece j of the node
+        if (len - flushed == TRACE_LDS) {
+            if (len >= S.max_trace) { overflow = true; break; }
+            wave_sync();
+            for (int i = lane; i < TRACE_LDS; i += 64) reinterpret_cast<uint4*>(P.trace())[flushed + i] = L.tbuf[i];
+            wave_sync();
+            flushed = len;
+        }
+        if (len >= S.max_trace) { overflow = true; break; }
+        if (lane == 56) { cur = rc; L.tbuf[len - flushed] = make_uint4((uint32_t)idx, rc.y, rc.z, rc.w); }
+        len += 1;
+        const bool exists = rc.x != 0u && lane < 56;
+        const uint64_t onm = __builtin_amdgcn_ballot_w64(exists);
+        if (onm == 0ull) break;                                  // no children: a leaf
+        const uint4 sc = buf_ld16(stat_rs, (lane < 56 ? rc.x : 0u) * 16u);                 // the child NODE's statistics
+        const float visit = exists ? __uint_as_float(sc.x) : 0.0f;
+        const uint64_t lowmask = __builtin_amdgcn_ballot_w64(exists && visit < lowf);
+        uint32_t c;
+        if (lowmask != 0ull) {
+            uint64_t mm = lowmask & 0x0101010101010101ull;       // one bit per group = per unique child, in slot order
+            const int m = __popcll(mm);
+            const uint32_t rr = wave_rand_lds(L.misc, rng_pos, lane);
+            const int kth = (int)(rr % (uint32_t)m);
+            for (int t = 0; t < kth; ++t) mm &= mm - 1;
+            c = rl_u32(rc.x, __builtin_ctzll(mm) & 56);
+        } else {
+            const int n = (int)group_sum_u32((uint32_t)(int)visit);                        // visits are whole numbers
+            double coeff;
+            if (n < S.nq_size) coeff = nqd[n];
+            else { const double alpha = 1 - 1 / (double)n; coeff = 10 * log(1 - log(-log(alpha) / log(2.0)) / log(22.0)) / log(41.0); nq_fallback += 1; }
+            const float t1 = __uint_as_float(sc.y) + __uint_as_float(rc.z);                // mean + score, float
+            const float s0 = (float)((double)t1 - (double)__uint_as_float(rc.w));         // - curr_reward (the node's own score)
+            const float s1 = (float)((double)__uint_as_float(sc.z) / ((double)visit + 1e-3));
+            const double q = (double)s0 + coeff * (double)sqrtf(s1);
+            // np.argmax over the children in slot order: every lane runs the seven-step scan on the groups' values
+            int best = 0;
+            double best_q = 0;
+            bool done = false;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const double qj = __longlong_as_double((long long)rl_u64((uint64_t)__double_as_longlong(q), 8 * j));
+                const bool ex = (onm >> (8 * j)) & 1ull;
+                if (!ex || done) continue;
+                if (j == 0) { best_q = qj; continue; }
+                if (best_q != best_q) { done = true; continue; }
+                if (qj != qj || qj > best_q) { best_q = qj; best = j; }
+            }
+            c = rl_u32(rc.x, 8 * best);
+        }
+        idx = (int)c;
+    }
+    wave_sync();
+    cur = make_uint4(rl_u32(cur.x, 56), rl_u32(cur.y, 56), rl_u32(cur.z, 56), rl_u32(cur.w, 56));
+    const uint32_t rng_keep = (lane < 32) ? L.misc[lane] : 0u;     // L.misc is reused by the expansion
+    wave_sync();
+    for (int i = flushed + lane; i < len; i += 64) reinterpret_cast<uint4*>(P.trace())[i] = L.tbuf[i - flushed];
+    const long long tc_sel = __builtin_readcyclecounter();
+    const int leaf = idx;
+    const int leaf_end = (int)((cur.w >> 24) & 1u) | (overflow ? 1 : 0);
+    const int leaf_score = (int)P.game()[(size_t)leaf * GAME_DW + 14];
+    if (overflow) { if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_TRACE); }
+    if (lane == 0) {
+        int32_t* gs = P.gs();
+        gs[TM_GS_CYC_SELECT] = (int)(tc_sel - tc_start);
+        gs[TM_GS_TRACE_LEN] = len;
+        gs[TM_GS_LEAF] = leaf;
+        gs[TM_GS_LEAF_END] = leaf_end;
+        gs[TM_GS_LEAF_SCORE] = leaf_score;
+        gs[TM_GS_TRACE_SUM] = GSV(gsv, TM_GS_TRACE_SUM) + len;
+        if (len > GSV(gsv, TM_GS_MAX_TRACE)) gs[TM_GS_MAX_TRACE] = len;
+        if (nq_fallback) gs[TM_GS_N_NQ_FALLBACK] = GSV(gsv, TM_GS_N_NQ_FALLBACK) + nq_fallback;
+        gs[TM_GS_SIM_STARTED] = GSV(gsv, TM_GS_SIM_STARTED) + 1;
+    }
+    if (rng_pos != rng_pos0) {
+        if (lane < 32) S.rng[(size_t)g * 32 + lane] = rng_keep;
+        if (lane == 0) P.gs()[TM_GS_RNG_POS] = rng_pos;
+    }
+    wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end, cur.y, cur.z, gsv, gc_req_word);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // GC (agents/agent.py:206-257, ValueSim.py:101-159): reachable set from the root, free lists rebuilt in
 // ascending order, freed observations cleared, replay tuples harvested, tables rebuilt.
 //
@@ -1356,7 +1542,7 @@ __device__ __forceinline__ void gc_collect(const tm_store& S, const GP& P, int g
     }
     {
         // the kept observations, by index (the bitmap says which), back into their (cleared) table
-        for (int base = 0; base < N; base += T * UR) {
+        for (int base = 0; base < (S.kind == TM_KIND_DIST ? 0 : N); base += T * UR) {
             uint4 key[UR][3];
             bool kept[UR];
 #pragma unroll
@@ -1761,7 +1947,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                     }
                 }
             }
-        } else {    // GCP_OBS
+        } else if (S.kind != TM_KIND_DIST) {    // GCP_OBS (no observation table without the projection)
             constexpr int UR = 2;
             {
                 const int lo = (int)((long long)N * p0 / n_parts), hi = (int)((long long)N * p1 / n_parts);
@@ -1882,16 +2068,20 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc, gsv, gc_req_word);
         return;
     }
+    const bool dist = !VANILLA && S.kind == TM_KIND_DIST;
     const long long t0 = __builtin_readcyclecounter();
     if ((flags & TM_SIM_BACKUP) && pend == 1) {
-        wave_sim_back(S, P, L, lane, gsv);
+        if (dist) wave_dist_back(S, P, L, g, lane, gsv);
+        else wave_sim_back(S, P, L, lane, gsv);
         __threadfence_block();
     }
     const long long t1 = __builtin_readcyclecounter();
     if (lane == 0) gs[TM_GS_CYC_BACK] = (int)(t1 - t0);
     // the per-move quota (tm_move_begin): games that lost launches to a collection catch up in extra launches
-    if ((flags & TM_SIM_FRONT) && GSV(gsv, TM_GS_SIM_STARTED) < GSV(gsv, TM_GS_SIM_TARGET))
-        wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane, gsv, gc_req_word);
+    if ((flags & TM_SIM_FRONT) && GSV(gsv, TM_GS_SIM_STARTED) < GSV(gsv, TM_GS_SIM_TARGET)) {
+        if (dist) wave_dist_front<VANILLA>(S, P, L, g, lane, gsv, gc_req_word);
+        else wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane, gsv, gc_req_word);
+    }
     else if (lane < S.eval_slots) P.eval_obs()[lane] = 0;   // nothing started: no request (the evaluator skips empty slots)
 }
 
@@ -1998,6 +2188,28 @@ __global__ void k_root_stats(tm_store S, float* stats, int32_t* action) {
     const int root = P.gs()[TM_GS_ROOT];
     float self = __uint_as_float(P.rec()[(size_t)root * TM_REC_DW + TM_REC_SCORE]);
     float* out = stats + (size_t)g * 21;
+    if (S.kind == TM_KIND_DIST) {
+        // DistValueSimOnline.py:76-98: visit / multiplicity of the child among the seven actions, mean + score - root score
+        // (left to right, float), variance; the action = np.argmax of the second row
+        int bestd = 0, nan_at = -1;
+        float bestq = 0;
+        for (int a = 0; a < 7; ++a) {
+            const uint32_t c = P.kids()[(size_t)root * TM_KIDS_DW + a];
+            int cnt = 0;
+            for (int b = 0; b < 7; ++b) cnt += P.kids()[(size_t)root * TM_KIDS_DW + b] == c;
+            const float sc = __uint_as_float(P.rec()[(size_t)c * TM_REC_DW + TM_REC_SCORE]);
+            const uint4 st = *reinterpret_cast<const uint4*>(P.stat() + (size_t)c * 4);
+            const float t = __uint_as_float(st.y) + sc;
+            const float v1 = t - self;
+            out[a] = __uint_as_float(st.x) / (float)cnt;
+            out[7 + a] = v1;
+            out[14 + a] = __uint_as_float(st.z);
+            if (v1 != v1 && nan_at < 0) nan_at = a;
+            if (a == 0 || v1 > bestq) { bestq = v1; bestd = a; }
+        }
+        action[g] = nan_at >= 0 ? nan_at : bestd;
+        return;
+    }
     const bool cpp = (S.kind == TM_KIND_CPPAGENT_LP || S.kind == TM_KIND_CPPAGENT || S.kind == TM_KIND_VANILLA_C);
     int best = 0, first_nan = -1;
     float bestv = 0;
@@ -2148,7 +2360,12 @@ __global__ void k_eval_render(tm_store S, int8_t* out) {
     int j = blockIdx.x;
     int g = j / S.eval_slots;
     int o = S.eval_obs[j];
-    if (threadIdx.x < OBS_DW) key[threadIdx.x] = S.obs_key[((size_t)g * S.max_nodes + o) * OBS_DW + threadIdx.x];
+    if (S.kind == TM_KIND_DIST) {      // the request names a node: its observation is packed from its game
+        __shared__ uint32_t gm[GAME_DW];
+        if (threadIdx.x < GAME_DW) gm[threadIdx.x] = S.node_game[((size_t)g * S.max_nodes + o) * GAME_DW + threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) pack_obs(gm, key);
+    } else if (threadIdx.x < OBS_DW) key[threadIdx.x] = S.obs_key[((size_t)g * S.max_nodes + o) * OBS_DW + threadIdx.x];
     __syncthreads();
     if (threadIdx.x < 200) out[(size_t)j * 200 + threadIdx.x] = (o == 0) ? (int8_t)0 : (int8_t)obs_cell(key, threadIdx.x);
 }
@@ -2188,6 +2405,14 @@ void tm_fill_norm_quantile(float* t, int n) {
     for (int i = 0; i < n; ++i) {
         double alpha = 1 - 1 / (double)i;
         t[i] = (float)(10 * log(1 - log(-log(alpha) / log2_) / log22) / log41);
+    }
+}
+
+void tm_fill_norm_quantile_f64(double* t, int n) {
+    const double log2_ = log(2.0), log22 = log(22.0), log41 = log(41.0);
+    for (int i = 0; i < n; ++i) {
+        double alpha = 1 - 1 / (double)i;
+        t[i] = 10 * log(1 - log(-log(alpha) / log2_) / log22) / log41;
     }
 }
 
@@ -2292,7 +2517,7 @@ extern "C" int tm_store_layout(int* out, int n) {
     int v[] = {(int)sizeof(tm_store), (int)offsetof(tm_store, gamma), (int)offsetof(tm_store, node_rec),
                (int)offsetof(tm_store, nq_table), (int)offsetof(tm_store, replay_count), (int)offsetof(tm_store, mt_state),
                (int)offsetof(tm_store, node_child), (int)offsetof(tm_store, gc_slice_cycles),
-               (int)offsetof(tm_store, gc_part)};
+               (int)offsetof(tm_store, gc_part), (int)offsetof(tm_store, dist_vmin)};
     int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < m; ++i) out[i] = v[i];
     return m;

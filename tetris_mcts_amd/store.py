@@ -11,7 +11,7 @@ import torch
 from . import _lib
 
 SIM_BACKUP, SIM_FRONT, SIM_GC_FULL = 1, 2, 4
-KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA, KIND_VANILLA_C = 0, 1, 2, 3, 4, 5
+KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA, KIND_VANILLA_C, KIND_DIST = 0, 1, 2, 3, 4, 5, 6
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18, MAX_TRACE=19, N_DROPPED=25,
           CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_SLICES=38,
@@ -31,6 +31,17 @@ def norm_quantile_table(n, device):
     return _nq_cache[key]
 
 
+def norm_quantile_table_f64(n, device):
+    """norm_quantile(i) in double (policy_dist of the distributional agent multiplies in double)"""
+    key = ("f64", n, str(device))
+    if key not in _nq_cache:
+        host = np.zeros(n, np.float64)
+        with np.errstate(all="ignore"):
+            _lib.lib().tm_fill_norm_quantile_f64(host.ctypes.data_as(C.c_void_p), n)
+        _nq_cache[key] = torch.from_numpy(host).to(device)
+    return _nq_cache[key]
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -44,7 +55,7 @@ class TreeStore:
 
     def __init__(self, n_games, max_nodes=100000, kind=KIND_VALUESIM, env_args=((20, 10), 1, 0, 0), gamma=0.999,
                  low=1, eval_slots=None, max_trace=1024, nq_size=1 << 20, online=False, min_visits_to_store=10,
-                 replay_cap=0, gc_slice_cycles=150000, device="cuda"):
+                 replay_cap=0, gc_slice_cycles=150000, dist_bins=50, dist_range=(0.0, 5000.0), device="cuda"):
         if not torch.cuda.is_available():
             raise RuntimeError("tetris_mcts_amd needs a ROCm GPU (gfx950); there is no CPU path")
         shape, app, scoring, randomizer = env_args[0], env_args[1], env_args[2], env_args[3]
@@ -76,14 +87,23 @@ class TreeStore:
             mt_state=z(G if kind in (KIND_VANILLA, KIND_VANILLA_C) else 1, 625),
         )
         self.t["nq_table"] = norm_quantile_table(nq_size, dev)
+        # TM_KIND_DIST only: the nodes' value distributions, the evaluator's output, norm_quantile in double
+        is_dist = kind == KIND_DIST
+        if is_dist and not (0 < dist_bins <= 64):
+            raise ValueError("1..64 atoms")
+        self.t["node_dist"] = z(G, N if is_dist else 1, 64, dtype=torch.float32)
+        self.t["eval_dist"] = z(G, 64, dtype=torch.float32)
+        self.t["nq_table_d"] = norm_quantile_table_f64(nq_size, dev) if is_dist else torch.zeros(1, dtype=torch.float64, device=dev)
         s = _lib.TmStore()
         s.n_games, s.max_nodes, s.table_cap, s.max_trace, s.eval_slots, s.nq_size = G, N, cap, max_trace, eval_slots, nq_size
         s.app, s.scoring, s.randomizer = int(app), int(scoring), int(randomizer)
         s.low, s.kind, s.min_visits_to_store, s.online, s.replay_cap = int(low), int(kind), int(min_visits_to_store), int(bool(online)), int(replay_cap)
         s.gc_slice_cycles = int(gc_slice_cycles)
         s.gamma = float(gamma)
-        for name, _ in _lib.TmStore._fields_[16:]:
-            setattr(s, name, self.t[name].data_ptr())
+        for name, typ in _lib.TmStore._fields_[16:]:
+            if typ is C.c_void_p:
+                setattr(s, name, self.t[name].data_ptr())
+        s.dist_bins, s.dist_vmin, s.dist_vmax = int(dist_bins), float(dist_range[0]), float(dist_range[1])
         self.s = s
         self.stats_buf = torch.zeros(G, 3, 7, dtype=torch.float32, device=dev)
         self.action_buf = torch.zeros(G, dtype=torch.int32, device=dev)
