@@ -64,10 +64,10 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     for flag in ('save', 'save_tree', 'gui', 'interactive'):
         if getattr(args, flag):
-            sys.exit('--%s is part of the reference\'s storage / UI layer (util/Data.py, util/gui.py), which this engine '
-                     'does not reimplement' % flag)
+            sys.exit('--%s is part of the reference\'s storage / UI layer (util/Data.py: PyTables / HDF5 episode files - neither '
+                     'PyTables nor h5py nor libhdf5 exists in this image; util/gui.py), which this engine does not reimplement' % flag)
     if not args.agent_type:
-        sys.exit('--agent_type is required (ValueSim, ValueSimLP, ValueSimC, Vanilla, VanillaC)')
+        sys.exit('--agent_type is required (ValueSim, ValueSimLP, ValueSimC, Vanilla, VanillaC, DistValueSim)')
     from importlib import import_module
     from pyTetris import Tetris                       # the reference's own two import lines (play.py:1,81-82)
     _agent_module = import_module('agents.' + args.agent_type)

@@ -463,6 +463,9 @@ def test_play_cli_runs_a_short_game(capsys, tmp_path, monkeypatch):
     play.main(["--agent_type", "VanillaC", "--mcts_sims", "8", "--endless", "--max_moves", "400", "--n_games", "3"])
     out = capsys.readouterr().out
     assert "Episode:" in out and "Lines Cleared:" in out
+    # the distributional agent under both of its module names (the reference's file is DistValueSimOnline.py, its class DistValueSim)
+    play.main(["--agent_type", "DistValueSim", "--mcts_sims", "30", "--max_moves", "3", "--n_games", "4"])
+    play.main(["--agent_type", "DistValueSimOnline", "--mcts_sims", "30", "--max_moves", "2"])
 
 
 # ---- TreeAgent's single calls (agent.cpp:825-833): update_root / expand(game) / new_node(game) / remove_nodes ----
