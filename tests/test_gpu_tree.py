@@ -86,10 +86,10 @@ def test_valuesimlp_hash_eval_with_gc(oracle):
 
 
 def test_many_games_collecting_at_once(oracle):
-    """The collector workgroups under load: 96 games with 3000-node pools, every game collects every few moves and many
+    """The collector workgroups under load: 96 games with 3000-node pools, every game collects every few dozen moves and many
     of them at the same time (shared marking workgroups, rotating order, bounded steps queueing for their cost allowance),
     every action and every root statistic against the games' own oracles, whole trees at the end."""
-    gcs = _compare_run(oracle, "ValueSim", G=96, sims=60, max_nodes=3000, seed=77, moves=60, evaluator="hash",
+    gcs = _compare_run(oracle, "ValueSim", G=96, sims=30, max_nodes=3000, seed=77, moves=150, evaluator="hash",
                        check_tree_every=30)
     assert gcs >= 300
 
