@@ -407,9 +407,7 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
         attr_set = true;
     }
     int blocks = (n + 3) / 4;
-    static int wg_per_cu = 0;
-    if (!wg_per_cu) { const char* e = getenv("TM_CONV_WG_CAP"); wg_per_cu = e ? atoi(e) : TM_CONV_WG_PER_CU; if (wg_per_cu < 1) wg_per_cu = 1; }
-    if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;   // resident workgroups, waves stride over the states
+    if (blocks > 256 * TM_CONV_WG_PER_CU) blocks = 256 * TM_CONV_WG_PER_CU;   // resident workgroups, waves stride over the states
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, eval_obs,
                        eval_slots, max_nodes, n, scratch, SS);
     hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(512), 0, stream, P, prepared, scratch, SS, n,
