@@ -82,6 +82,8 @@ def main():
                     help="sub-batches of the rank's games on separate HIP streams (one sub-batch's tree kernel runs "
                     "under another's value-net kernels)")
     ap.add_argument("--gc-slice-cycles", type=int, default=150000)
+    ap.add_argument("--gc-spec-nodes", type=int, default=None,
+                    help="free nodes below which a game's tree is marked while it goes on simulating (default: the store's)")
     ap.add_argument("--online", action="store_true", help="harvest training tuples at GC and all-gather them every move")
     ap.add_argument("--steady-warmup", type=int, default=75, help="the steady-state window starts after this many moves")
     ap.add_argument("--steady-steps", type=int, default=20, help="moves of the second, steady-state window (0: none)")
@@ -129,7 +131,7 @@ def main():
     game = Tetris(*env_args, seed=tdist.game_seeds(20260925, G, rank), n_games=G)     # game g of rank r = game r*G + g of the job
     okw = dict(online=True, min_visits_to_store=10, replay_cap=16384) if args.online else dict(online=False)
     agent = getattr(agents, args.agent)(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=args.max_nodes,
-                                        model=model, n_sub=NS, ev_every=EV_EVERY, gc_slice_cycles=args.gc_slice_cycles,
+                                        model=model, n_sub=NS, ev_every=EV_EVERY, gc_slice_cycles=args.gc_slice_cycles, gc_spec_nodes=args.gc_spec_nodes,
                                         **okw)
     agent.update_root(game)
     torch.cuda.synchronize()
@@ -282,7 +284,7 @@ def main():
             "workload_key": workload_key,
             "games_per_gpu": G, "sims_per_move": sims, "agent": args.agent, "max_nodes": args.max_nodes,
             "valuenet_backend": args.backend, "sub_batches": NS, "online": bool(args.online),
-            "gc_slice_cycles": args.gc_slice_cycles,
+            "gc_slice_cycles": args.gc_slice_cycles, "gc_spec_nodes": args.gc_spec_nodes,
         },
         "sims_per_sec": n_sims / elapsed,
         "child_steps_per_sec": 7.0 * n_exp / elapsed,

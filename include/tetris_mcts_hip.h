@@ -57,8 +57,9 @@ enum {
     TM_GS_FIRST_MISS = 28, /* levels of the last walk that were taken over from the walk before it (verified in parallel, tree.hip) */
     TM_GS_PREFIX_SUM,      /* sum of TM_GS_FIRST_MISS over all simulations */
     /* garbage collection by the collector workgroups of tm_sim_step (a game that collects does not simulate; tree.hip) */
-    TM_GS_GC_PHASE = 32, /* 0 none; (launch << 4) | 1 requested; 2 marking, 3 counting, 4 writing the free lists, 5 re-inserting;
-                            (launch << 4) | 7 complete (the game resumes in a later launch) */
+    TM_GS_GC_PHASE = 32, /* 0 none; (launch << 4) | 1 requested; 2 marking, 3 counting, 4 writing the free lists, 5 / 6 re-inserting nodes /
+                            observations; (launch << 4) | 7 complete (the game resumes in a later launch); speculative marking while the
+                            game simulates: (launch << 4) | 8 requested, 9 under way, (launch << 4) | 10 the pool ran dry meanwhile */
     TM_GS_GC_ARRIVE,     /* collector workgroups that have done their share of the current step (bits 8..: some left work) */
     TM_GS_GC_TAIL,       /* nodes discovered so far (queue length; device-scope atomic) */
     TM_GS_GC_TAIL0,      /* the same as of the start of the launch */
@@ -143,7 +144,9 @@ typedef struct tm_store {
     float *eval_dist;     /* [G][TM_DIST_ROW] the evaluator's distribution for the game's pending leaf (model_distributional.Net) */
     const double *nq_table_d; /* [nq_size] norm_quantile(n) in double (policy_dist multiplies in double), host libm */
     double dist_vmin, dist_vmax;
-    int32_t dist_bins, reserved_;
+    int32_t dist_bins;
+    int32_t gc_spec_nodes; /* a game with fewer free nodes than this has its tree marked speculatively while it goes on simulating
+                              (tree.hip GC_SPEC_*); 0: never */
 } tm_store;
 
 /* pools, free lists, tables, rng (seed 1), control blocks.  Everything else must be zero-filled by the caller. */

@@ -23,7 +23,7 @@ class TmStore(C.Structure):
         ("trace", vp), ("leaf", vp), ("eval_obs", vp), ("eval_v", vp), ("eval_var", vp), ("nq_table", vp),
         ("gc_mark", vp), ("gc_queue", vp), ("replay_obs", vp), ("replay_stat", vp), ("replay_count", vp), ("mt_state", vp), ("node_child", vp), ("gc_part", vp),
         ("node_dist", vp), ("eval_dist", vp), ("nq_table_d", vp), ("dist_vmin", f64), ("dist_vmax", f64), ("dist_bins", i32),
-        ("reserved_", i32),
+        ("gc_spec_nodes", i32),
     ]
 
 

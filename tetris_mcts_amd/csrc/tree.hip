@@ -263,11 +263,31 @@ __device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, u
 
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, int lane);
 
+constexpr int GC_REQ = 1, GC_DONE = 7;   // phase word: (launch << 4) | GC_REQ requested, 2..6 under way (GCP_*), (launch << 4) | GC_DONE complete
+// SPECULATIVE MARKING: a game that is about to run out of nodes (S.gc_spec_nodes left) has its tree marked while it goes
+// on simulating - the marking is what keeps a collecting game out for twenty launches.  Marks only ever grow while the
+// root stays (nothing becomes unreachable inside a move), and the expansion keeps the marker's invariant ("what is
+// reachable is marked or will be reached") with a write barrier: every successor it links is marked (a new node, with
+// its observation) or, if it is an existing node found by transposition and not marked yet, marked and appended to the
+// marker's queue.  At the exhausting pop the marking is simply continued to its end (usually a launch or two) and the
+// collection proceeds; update_root drops a speculative marking (the root moves, marks would be stale).
+//   (launch << 4) | GC_SPEC_REQ   asked for by the game's wave; collectors of LATER launches initialise the bitmaps
+//   GC_SPEC_MARK                  marking under way, the game simulates with the barrier
+//   (launch << 4) | GC_REQ_SPEC   the pool ran dry during GC_SPEC_MARK: clear the tables, finish the marking, go on
+//   (launch << 4) | GC_REQ_OVER   the pool ran dry while GC_SPEC_REQ was pending: an ordinary request
+// A phase word that a game's wave changes in the middle of a launch must read the same to every collector workgroup of
+// that launch, whichever value it happens to load (they all have to agree on the launch's plan): the word the wave
+// writes carries the launch number and tells what it replaced - nothing (GC_REQ, GC_SPEC_REQ: not this launch's
+// business), GC_SPEC_MARK (GC_REQ_SPEC) or a pending GC_SPEC_REQ (GC_REQ_OVER).
+constexpr int GC_SPEC_REQ = 8, GC_SPEC_MARK = 9, GC_REQ_SPEC = 10, GC_REQ_OVER = 12;
+constexpr int GC_IDLE = 11;        // (a step, not a phase: a speculative marking that has nothing to do in this launch)
+
+
 // `gsv`: the wave's snapshot of the game's control block (word i in lane i), valid when nothing in this launch has changed
 // the free-list words yet (the expansion's first attempt); has_gsv = false: read them from memory (sequential retries,
 // update_root).
 __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, WaveLds& L, int g, int n, int lane,
-                                      int& r_idx, int& r_obs, bool has_gsv = false, int gsv = 0) {
+                                      int& r_idx, int& r_obs, bool has_gsv = false, int gsv = 0, bool barrier = false) {
     const bool act = lane < n;
     const uint32_t* my = L.slots[act ? lane : 0];
     const uint32_t mask = (uint32_t)S.table_cap - 1u;
@@ -404,6 +424,31 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         kd[0] = z; kd[1] = z;
     }
     if (uniq && found) o = (int)P.rec()[(size_t)found * TM_REC_DW + TM_REC_OBS];
+    if (barrier) {
+        // write barrier of a speculative marking (see GC_SPEC_MARK): every successor about to be linked is marked; a new
+        // node with its observation (the marker never visits it: it has no children yet), an existing one that was not
+        // marked goes to the marker's queue
+        const size_t bm_bytes = (((size_t)S.max_nodes + 7) / 8 + 15) & ~(size_t)15;
+        uint32_t* nmw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes);
+        uint32_t* omw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes + bm_bytes);
+        // Both kinds go into the queue (it lists the kept nodes for the table rebuild and the count): a new node as
+        // already processed (bit 31: it has no children), an existing one for the marker to visit.
+        bool shade = false, fresh = false;
+        if (uniq && idx != 0) {
+            const uint32_t oldw = atomicOr(nmw + ((uint32_t)idx >> 5), 1u << (idx & 31));
+            fresh = !((oldw >> (idx & 31)) & 1u);
+            if (isnew) atomicOr(omw + ((uint32_t)o >> 5), 1u << (o & 31));
+            else shade = fresh;
+        }
+        const uint64_t sm = __ballot(fresh), shm = __ballot(shade);
+        if (sm != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&P.gs()[TM_GS_GC_TAIL], __popcll(sm));
+            base = (int)rl_u32((uint32_t)base, 0);
+            if (fresh) (S.gc_queue + (size_t)g * P.n())[base + __popcll(sm & ((1ull << lane) - 1ull))] = shade ? idx : (idx | (int)0x80000000);
+            if (lane == 0 && shm != 0ull) atomicMin(&P.gs()[TM_GS_GC_MINLEFT], base);
+        }
+    }
     {
         int isrc = shfl_u32((uint32_t)idx, dup), osrc = shfl_u32((uint32_t)o, dup);
         if (act && dup != lane) { idx = isrc; o = osrc; }
@@ -437,7 +482,8 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
     }
     wave_sync();
     int idx, o;
-    wave_new_nodes(S, P, L, g, 7, lane, idx, o, true, gsv);
+    const bool barrier = (gc_req_word & 15) == GC_REQ_SPEC;      // the launch began in GC_SPEC_MARK
+    wave_new_nodes(S, P, L, g, 7, lane, idx, o, true, gsv, barrier);
     if (idx < 0) {
         // slow path: sequential new_node with a GC at the exhausting pop (rare: once per ~50 moves)
         int out_idx = 0, out_o = 0;
@@ -450,11 +496,11 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
             if (lane < GAME_DW) { keep = L.slots[0][lane]; L.slots[0][lane] = L.slots[7][lane]; }
             wave_sync();
             int i1, o1;
-            wave_new_nodes(S, P, L, g, 1, lane, i1, o1);
+            wave_new_nodes(S, P, L, g, 1, lane, i1, o1, false, 0, barrier);
             if (i1 < 0) {
                 if (!P.gs()[TM_GS_GC_RETRY] && !P.gs()[TM_GS_POOL_FULL]) {
                     if (lane < GAME_DW) L.slots[0][lane] = keep;
-                    if (lane == 0) { P.gs()[TM_GS_GC_PHASE] = gc_req_word; P.gs()[TM_GS_GC_RETRY] = 1; }
+                    if (lane == 0) { atomicExch(&P.gs()[TM_GS_GC_PHASE], gc_req_word); P.gs()[TM_GS_GC_RETRY] = 1; }
                     wave_sync();
                     return false;
                 }
@@ -773,6 +819,12 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
         gs[TM_GS_GC_RETRY] = 0;
         gs[TM_GS_K_EVAL] = k_eval;
         gs[TM_GS_N_EVAL] = GSV(gsv, TM_GS_N_EVAL) + k_eval;
+        // nearly out of nodes: have the tree marked while the game goes on (GC_SPEC_*), unless a collection could not help
+        // ... and only if the pool will run dry in THIS move (six nodes a simulation): update_root drops the marks
+        if (S.gc_spec_nodes > 0 && GSV(gsv, TM_GS_GC_PHASE) == 0 && !leaf_end && !GSV(gsv, TM_GS_POOL_FULL) && !gs[TM_GS_POOL_FULL]) {
+            const int nf = gs[TM_GS_NFREE_NODE], sims_left = GSV(gsv, TM_GS_SIM_TARGET) - GSV(gsv, TM_GS_SIM_STARTED);
+            if (nf < S.gc_spec_nodes && nf < 6 * sims_left) gs[TM_GS_GC_PHASE] = (gc_req_word & ~15) | GC_SPEC_REQ;
+        }
     }
 }
 
@@ -1287,7 +1339,6 @@ __device__ __forceinline__ void wave_dist_front(const tm_store& S, const GP& P, 
 // carries the launch number for that: a request is (launch << 4) | 1 and is picked up by the collectors of LATER
 // launches; a finished collection leaves (launch << 4) | 7 and the game's wave resumes in a LATER launch.
 // ---------------------------------------------------------------------------------------------------
-constexpr int GC_REQ = 1, GC_DONE = 7;   // phase word: (launch << 4) | GC_REQ requested, 2..5 under way (GCP_*), (launch << 4) | GC_DONE complete
 constexpr int GC_BLOCKS_MAX = 64;   // collector workgroups of a k_sim_step launch: half for the bounded steps, half for the marking (measured: with a
                                     // quarter for the marking a collection takes 35 launches instead of 23)
 __host__ __device__ inline int gc_blocks(int n_games) {
@@ -1435,7 +1486,7 @@ __device__ __forceinline__ void gc_collect(const tm_store& S, const GP& P, int g
     // zeroes at GC, agents/agent.py:227-244; nothing reads a free slot in between).
     {
         const int n_words = (N + 31) / 32;
-        const int low_obs = gs[TM_GS_LOW_OBS];
+        const int low_obs = gs[TM_GS_LOW_OBS], low_node = gs[TM_GS_LOW_NODE];
         const bool harvest = S.online && S.replay_cap > 0;
         int m = harvest ? S.replay_count[g] : 0;
         for (int wbase = 0; wbase < n_words; wbase += T) {
@@ -1446,7 +1497,16 @@ __device__ __forceinline__ void gc_collect(const tm_store& S, const GP& P, int g
             const uint32_t fr = (wi < n_words) ? (~nmw[wi] & valid) : 0u;
             int total;
             int pos = nfree + G_::exscan(__popc(fr), tid, sm, total);
-            for (uint32_t bits = fr; bits; bits &= bits - 1) P.fnode()[pos++] = wi * 32 + (__ffs(bits) - 1);
+            for (uint32_t bits = fr; bits; bits &= bits - 1) {
+                const int i = wi * 32 + (__ffs(bits) - 1);
+                P.fnode()[pos++] = i;
+                if (i >= low_node) {        // a free slot holds no child indices and no observation (see the collectors' write step)
+                    const uint4 z4 = make_uint4(0, 0, 0, 0);
+                    uint4* kd = reinterpret_cast<uint4*>(P.kids() + (size_t)i * TM_KIDS_DW);
+                    kd[0] = z4; kd[1] = z4;
+                    reinterpret_cast<uint4*>(P.rec() + (size_t)i * TM_REC_DW)[7] = z4;
+                }
+            }
             nfree += total;
             // ---- observations ----
             const uint32_t ofr = (wi < n_words) ? (~omw[wi] & valid) : 0u;
@@ -1581,6 +1641,13 @@ __device__ __forceinline__ void gc_collect(const tm_store& S, const GP& P, int g
 }
 // to completion, now, by the game's own wave (update_root's exhausting pop: once per move at most, and almost never; the
 // single-call entry points)
+// a speculative marking is dropped whenever the tree changes without its barrier watching (update_root, the single calls)
+__device__ __forceinline__ void gc_drop_speculative(const GP& P, int lane) {
+    const int ph = P.gs()[TM_GS_GC_PHASE] & 15;
+    wave_sync();
+    if (lane == 0 && (ph == GC_SPEC_REQ || ph == GC_SPEC_MARK)) P.gs()[TM_GS_GC_PHASE] = 0;
+    wave_sync();
+}
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, int lane) {
     if (lane == 0) P.gs()[TM_GS_GC_PHASE] = GC_REQ;
     __threadfence_block();
@@ -1608,25 +1675,28 @@ __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, i
 // A collection in progress must be continued by launches over the same range of games (same n).
 // ---------------------------------------------------------------------------------------------------
 constexpr int GCP_INIT = GC_REQ, GCP_MARK = 2, GCP_COUNT = 3, GCP_WRITE = 4, GCP_NODES = 5, GCP_OBS = 6;
-constexpr int GC_LIST_MAX = 64;      // collecting games looked after per launch (the others wait)
+constexpr int GC_LIST_MAX = 256, GC_LIST_WAIT = 64;     // collecting games looked after per launch (the others wait): all, and those that are waiting for their collection
 constexpr int GC_COST_MAX = 6;       // per launch: cost units of the steps whose shares are done without looking at the clock
                                      // (init 1, count 1, write 2, nodes 5, observations 5: about 5 microseconds a unit)
 constexpr int GC_RING = 32;          // chunks of own discoveries a workgroup remembers while marking
 struct GcLds {
     int scan[8];                     // Grp<256> scratch
     int n_list;
-    int list_g[GC_LIST_MAX], list_ph[GC_LIST_MAX];
+    int list_g[GC_LIST_MAX], list_ph[GC_LIST_MAX];       // the collecting games and their phase words as of the start of the launch
+    int list_step[GC_LIST_MAX];                         // the launch's plan: the step performed for the game,
+    short list_part[GC_LIST_MAX], list_parts[GC_LIST_MAX], list_share[GC_LIST_MAX];     // this workgroup's share (part of parts; parts 0: not in this launch)
+    short order[GC_LIST_MAX]; int n_order;              // the games this workgroup works on, in order
     int ring_start[GC_RING], ring_cnt[GC_RING];
 };
 
 // thread 0 of a workgroup, after the workgroup's stores for this game: returns true for the last workgroup to arrive
-__device__ __forceinline__ bool gc_arrive(int32_t* gs, int n_gc, bool leftover, bool& any_left) {
+__device__ __forceinline__ bool gc_arrive(int32_t* gs, int n_gc, bool leftover, bool& any_left, bool blocking) {
     const int add = 1 + (leftover ? 256 : 0);
     const int old = atomicAdd(&gs[TM_GS_GC_ARRIVE], add);
     if ((old & 255) != n_gc - 1) return false;
     any_left = ((old + add) >> 8) != 0;
     atomicExch(&gs[TM_GS_GC_ARRIVE], 0);
-    gs[TM_GS_GC_SLICES] += 1;
+    if (blocking) gs[TM_GS_GC_SLICES] += 1;      // launches the game has waited for its collections
     return true;
 }
 
@@ -1643,82 +1713,199 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         if (deadline < 0) return false;
         return G_::bcast((long long)__builtin_readcyclecounter() > deadline ? 1 : 0, tid, sm) != 0;
     };
-    // ---- which games are collecting (requested in an earlier launch, or under way), in game order ----
+    // ---- which games are collecting (requested in an earlier launch, or under way), in game order: first the games that
+    // are waiting for their collection (at most GC_LIST_WAIT), then the speculative markings ----
     // thread t looks at a contiguous run of games (all its loads in flight together, one prefix sum for the whole list)
-    int n_list = 0;
+    int n_wait = 0, n_spec = 0;
     {
         constexpr int RUN = 16;
-        for (int base = 0; base < S.n_games && n_list < GC_LIST_MAX; base += T * RUN) {
+        for (int base = 0; base < S.n_games; base += T * RUN) {
             int word[RUN];
 #pragma unroll
             for (int r = 0; r < RUN; ++r) {
                 const int g = base + tid * RUN + r;
                 word[r] = g < S.n_games ? S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_PHASE] : 0;
             }
-            uint32_t todo = 0;
+            uint32_t todo_w = 0, todo_s = 0;
 #pragma unroll
             for (int r = 0; r < RUN; ++r) {
+                // (a phase word that the game's wave replaces in the middle of a launch reads as what it replaced, see GC_REQ_OVER)
                 const int ph = word[r] & 15;
-                if ((ph >= GCP_MARK && ph <= GCP_OBS) || (ph == GC_REQ && (word[r] >> 4) != seq)) todo |= 1u << r;
+                const bool now = (word[r] >> 4) == seq;
+                int cls = -1;                           // 0: waiting for its collection, 1: speculative marking
+                if (ph >= GCP_MARK && ph <= GCP_OBS) cls = 0;
+                else if (ph == GC_REQ) cls = now ? -1 : 0;
+                else if (ph == GC_SPEC_REQ) cls = now ? -1 : 1;
+                else if (ph == GC_SPEC_MARK) cls = 1;
+                else if (ph == GC_REQ_SPEC) { if (now) { word[r] = GC_SPEC_MARK; cls = 1; } else cls = 0; }
+                else if (ph == GC_REQ_OVER) {
+                    // (the compare-and-swap to GC_SPEC_MARK at the end of the step fails whichever word the last arriver expects)
+                    if (now) { word[r] = (word[r] & ~15) | GC_SPEC_REQ; cls = 1; } else cls = 0;
+                }
+                if (cls == 0) todo_w |= 1u << r;
+                if (cls == 1) todo_s |= 1u << r;
             }
-            int total;
-            int pos = n_list + G_::exscan(__popc(todo), tid, sm, total);
-            for (uint32_t bits = todo; bits; bits &= bits - 1) {
+            int total_w, total_s;
+            int pos_w = n_wait + G_::exscan(__popc(todo_w), tid, sm, total_w);
+            int pos_s = GC_LIST_WAIT + n_spec + G_::exscan(__popc(todo_s), tid, sm, total_s);
+            for (uint32_t bits = todo_w; bits; bits &= bits - 1) {
                 const int r = __ffs(bits) - 1;
-                if (pos < GC_LIST_MAX) { M.list_g[pos] = base + tid * RUN + r; M.list_ph[pos] = word[r] & 15; }
-                pos += 1;
+                if (pos_w < GC_LIST_WAIT) { M.list_g[pos_w] = base + tid * RUN + r; M.list_ph[pos_w] = word[r]; }
+                pos_w += 1;
             }
-            n_list = min(GC_LIST_MAX, n_list + total);
+            for (uint32_t bits = todo_s; bits; bits &= bits - 1) {
+                const int r = __ffs(bits) - 1;
+                if (pos_s < GC_LIST_MAX) { M.list_g[pos_s] = base + tid * RUN + r; M.list_ph[pos_s] = word[r]; }
+                pos_s += 1;
+            }
+            n_wait = min(GC_LIST_WAIT, n_wait + total_w);
+            n_spec = min(GC_LIST_MAX - GC_LIST_WAIT, n_spec + total_s);
         }
     }
     __syncthreads();
+    const int n_list = n_wait + n_spec;
     if (n_list == 0) return;
+    {   // the speculative markings right behind the waiting games
+        int mg = 0, mp = 0;
+        if (tid < n_spec) { mg = M.list_g[GC_LIST_WAIT + tid]; mp = M.list_ph[GC_LIST_WAIT + tid]; }
+        __syncthreads();
+        if (tid < n_spec) { M.list_g[n_wait + tid] = mg; M.list_ph[n_wait + tid] = mp; }
+        __syncthreads();
+    }
     const int N = S.max_nodes;
     const size_t bm_bytes = (((size_t)N + 7) / 8 + 15) & ~(size_t)15;
     const uint32_t mask = (uint32_t)S.table_cap - 1u;
     const int n_words = (N + 31) / 32;
     const bool harvest = S.online && S.replay_cap > 0;
-    // First pass: the bounded steps, as many as fit the launch's cost allowance, starting at a game that rotates with the
-    // launch number (nobody waits behind the low indices for ever) - every workgroup picks the same ones.
-    // Second pass: the marking.  It is a breadth-first walk whose depth, not its size, sets its duration (a round trip per
-    // level, a hundred levels and more), so the games that are marking do not share the time but the WORKGROUPS: game j of
-    // the n_mark marking games is looked after by the workgroups c with c % n_mark == j (all of them arrive for every game).
-    int n_mark = 0;
-    for (int k = 0; k < n_list; ++k) n_mark += M.list_ph[k] == GCP_MARK ? 1 : 0;
-    int cost_left = deadline < 0 ? 1 << 20 : GC_COST_MAX, mark_j = 0;      // (collector-only launches: nothing to hold up)
-    for (int kk = 0; kk < 2 * n_list; ++kk) {
-        const int k = (kk + seq) % n_list;
-        const int g = M.list_g[k], ph = M.list_ph[k];
-        if ((kk < n_list) == (ph == GCP_MARK)) continue;
-        long long my_deadline = deadline;
-        // this workgroup's share of the step's work: part my_part of n_parts (-1: none, it only arrives).  Workgroups
-        // [0, n_b) do the bounded steps, [n_b, n_gc) the marking (a lone workgroup does both): a launch's bounded work must
-        // not take the marking's time, nor the other way round.
-        const int n_b = n_gc >= 2 ? n_gc / 2 : 1, n_m = n_gc >= 2 ? n_gc - n_b : 1;
-        int my_part, n_parts;
-        if (ph != GCP_MARK) {
-            const int cost = ph == GCP_WRITE ? 2 : (ph == GCP_NODES || ph == GCP_OBS) ? 5 : 1;
-            if (cost > cost_left) continue;               // every workgroup skips the same games
-            cost_left -= cost;
-            n_parts = n_b;
-            my_part = c < n_b ? c : -1;
-        } else {
-            const int j = mark_j++;
-            const int cm = n_gc >= 2 ? c - n_b : 0;       // index among the marking workgroups (< 0: not one of them)
-            if (n_mark <= n_m) {
-                n_parts = n_m / n_mark + (j < n_m % n_mark ? 1 : 0);
-                my_part = (cm >= 0 && cm % n_mark == j) ? cm / n_mark : -1;
-            } else {
-                // more games marking than workgroups: workgroup j % n_m takes the whole of game j, its time shared
-                n_parts = 1;
-                my_part = (cm >= 0 && j % n_m == cm) ? 0 : -1;
-                if (my_part == 0 && deadline >= 0) {
-                    const long long t0_ = (long long)__builtin_readcyclecounter();     // thread 0's clock for everybody
-                    const long long t = ((long long)G_::bcast((int)(t0_ >> 32), tid, sm) << 32) | (unsigned)G_::bcast((int)t0_, tid, sm);
-                    const int mine_left = (n_mark - 1 - j) / n_m + 1;
-                    my_deadline = t >= deadline ? deadline : t + (deadline - t) / mine_left;
+    // THE LAUNCH'S PLAN (every workgroup derives the same one: the control words it reads were written in earlier launches,
+    // or are written in this one only after every workgroup has arrived for the game).
+    // The bounded steps first, as many as fit the launch's cost allowance, starting at a game that rotates with the launch
+    // number (nobody waits behind the low indices for ever); then the marking.  It is a breadth-first walk whose depth,
+    // not its size, sets its duration (a round trip per level, a hundred levels and more), so the games that are marking
+    // do not share the time but the WORKGROUPS: game j of the n_mark marking games is looked after by the marking
+    // workgroups cm with cm % n_mark == j.  Workgroups [0, n_b) do the bounded steps, [n_b, n_gc) the marking (a lone
+    // workgroup does both): a launch's bounded work must not take the marking's time, nor the other way round.
+    // EVERY workgroup arrives for every game whose step is performed, with or without a share of the work: nobody moves a
+    // game on before everybody has read its control words.  Arrivals without a share are made first, one thread per game,
+    // all in flight together (a speculative marking with nothing known to be unprocessed - GC_IDLE - is nothing but that:
+    // the last arriver takes in what the game's barrier has appended).
+    const int n_b = n_gc >= 2 ? n_gc / 2 : 1, n_m = n_gc >= 2 ? n_gc - n_b : 1;
+    if (tid < n_list) {
+        const int ph = M.list_ph[tid] & 15;
+        const int32_t* gsk = S.gs + (size_t)M.list_g[tid] * TM_GS_DW;
+        int step = ph == GC_REQ_OVER ? GCP_INIT : ph;   // the step this launch performs for the game
+        if (ph == GC_SPEC_MARK) step = gsk[TM_GS_GC_HEAD0] < gsk[TM_GS_GC_TAIL0] ? GCP_MARK : GC_IDLE;
+        M.list_step[tid] = step;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // the marking workgroups: one pool, or - when waiting games and speculative markings both have marking to do - a
+        // half each (a waiting game is the one that costs launches)
+        int cnt[2] = {0, 0};
+        for (int k = 0; k < n_list; ++k) cnt[k >= n_wait ? 1 : 0] += M.list_step[k] == GCP_MARK ? 1 : 0;
+        const bool split = cnt[0] > 0 && cnt[1] > 0 && n_m >= 2;
+        const int wgs[2] = {split ? n_m / 2 : n_m, split ? n_m - n_m / 2 : n_m}, off[2] = {0, split ? n_m / 2 : 0};
+        const int tot[2] = {split ? cnt[0] : cnt[0] + cnt[1], split ? cnt[1] : cnt[0] + cnt[1]};
+        int mark_j[2] = {0, 0};
+        int cost_left = deadline < 0 ? 1 << 20 : GC_COST_MAX, n_order = 0;      // (collector-only launches: nothing to hold up)
+        const int cm = n_gc >= 2 ? c - n_b : 0;           // index among the marking workgroups (< 0: not one of them)
+        for (int pass = 0; pass < 4; ++pass) {            // bounded steps of the waiting games, of the others; the markings likewise
+            const int cls = pass & 1, first = cls ? n_wait : 0, n = cls ? n_spec : n_wait;
+            for (int i = 0; i < n; ++i) {
+                const int k = first + (i + seq) % n;
+                const int step = M.list_step[k];
+                if ((pass < 2) == (step == GCP_MARK)) continue;
+                int my_part = -1, n_parts = 1, share = 0;
+                if (step == GC_IDLE) {
+                    // everybody just arrives
+                } else if (step != GCP_MARK) {
+                    const int cost = step == GCP_WRITE ? 2 : (step == GCP_NODES || step == GCP_OBS) ? 5 : 1;      // init / clear / count: 1
+                    if (cost > cost_left) { M.list_parts[k] = 0; continue; }      // not in this launch: nobody arrives
+                    cost_left -= cost;
+                    n_parts = n_b;
+                    my_part = c < n_b ? c : -1;
+                } else {
+                    const int j = mark_j[split ? cls : 0]++, n_mark = tot[cls], n_w = wgs[cls], cx = cm - off[cls];
+                    const bool mine = cm >= 0 && cx >= 0 && cx < n_w;
+                    if (n_mark <= n_w) {
+                        n_parts = n_w / n_mark + (j < n_w % n_mark ? 1 : 0);
+                        my_part = (mine && cx % n_mark == j) ? cx / n_mark : -1;
+                    } else {
+                        // more games marking than workgroups: workgroup j % n_w takes the whole of game j, its time shared
+                        my_part = (mine && j % n_w == cx) ? 0 : -1;
+                        share = (n_mark - 1 - j) / n_w + 1;      // games this workgroup still has before it, this one included
+                    }
                 }
+                M.list_part[k] = my_part; M.list_parts[k] = n_parts; M.list_share[k] = share;
+                if (my_part >= 0) M.order[n_order++] = k;
             }
+        }
+        M.n_order = n_order;
+    }
+    __syncthreads();
+    // a single thread, after its workgroup's stores for the game: arrive; the last workgroup to arrive moves the game on
+    auto arrive = [&](int k, bool leftover) {
+        const int g = M.list_g[k], word_seen = M.list_ph[k], step = M.list_step[k];
+        const bool spec = (word_seen & 15) == GC_SPEC_MARK;       // the game is simulating
+        int32_t* gs = S.gs + (size_t)g * TM_GS_DW;
+        bool any_left = false;
+        if (!gc_arrive(gs, n_gc, leftover, any_left, !spec && step != GC_SPEC_REQ)) return;
+        if (step == GCP_INIT || step == GC_SPEC_REQ) {
+            atomicExch(&gs[TM_GS_GC_TAIL], 1);
+            atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF);
+            gs[TM_GS_GC_TAIL0] = 1;
+            gs[TM_GS_GC_HEAD0] = 0;
+            // (speculative: the game's wave may have turned its request into a blocking one in this very launch - then
+            // that stands, and the next launch initialises from scratch)
+            if (step == GCP_INIT) gs[TM_GS_GC_PHASE] = GCP_MARK;
+            else atomicCAS(&gs[TM_GS_GC_PHASE], word_seen, GC_SPEC_MARK);
+        } else if (step == GC_REQ_SPEC) {
+            // the game has stopped: nothing is appended any more - take in what its last launches appended
+            const int tl = atomicAdd(&gs[TM_GS_GC_TAIL], 0);
+            const int ml = atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF);
+            gs[TM_GS_GC_HEAD0] = min(min(tl, ml), gs[TM_GS_GC_HEAD0]);
+            gs[TM_GS_GC_TAIL0] = tl;
+            gs[TM_GS_GC_PHASE] = GCP_MARK;
+        } else if (step == GCP_MARK || step == GC_IDLE) {
+            const int tl = atomicAdd(&gs[TM_GS_GC_TAIL], 0);
+            const int ml = atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF);
+            gs[TM_GS_GC_TAIL0] = tl;
+            gs[TM_GS_GC_HEAD0] = min(tl, ml);
+            // a speculative marking never ends by itself (the game may append to the queue after this point), and it does
+            // not touch the phase word (the game's wave may have put its blocking request there in this launch)
+            if (!spec && !any_left && ml == 0x7FFFFFFF) gs[TM_GS_GC_PHASE] = GCP_COUNT;
+        } else if (step == GCP_COUNT) {
+            gs[TM_GS_GC_PHASE] = GCP_WRITE;
+        } else if (step == GCP_WRITE) {
+            // the totals, from the counts of the launch before (nothing is exchanged inside a launch)
+            const int32_t* part = S.gc_part + (size_t)g * TM_GC_PART_DW;
+            int nf = 0, of = 0, kf = 0;
+            for (int b = 0; b < n_b; ++b) { nf += part[3 * b]; of += part[3 * b + 1]; kf += part[3 * b + 2]; }
+            gs[TM_GS_NFREE_NODE] = nf;
+            gs[TM_GS_NFREE_OBS] = of;
+            if (harvest) {
+                const int m0 = S.replay_count[g];
+                if (m0 + kf > S.replay_cap) gs[TM_GS_N_DROPPED] += m0 + kf - S.replay_cap;   // never silently (the reference keeps all up to memory_size)
+                S.replay_count[g] = min(S.replay_cap, m0 + kf);
+            }
+            gs[TM_GS_GC_PHASE] = GCP_NODES;
+        } else if (step == GCP_NODES) {
+            gs[TM_GS_GC_PHASE] = GCP_OBS;
+        } else {      // GCP_OBS
+            gs[TM_GS_N_GC] += 1;
+            gs[TM_GS_CYC_TAIL + 1] = gs[TM_GS_GC_TAIL0];      // reachable nodes at the last GC
+            gs[TM_GS_GC_PHASE] = (seq << 4) | GC_DONE;
+        }
+    };
+    if (tid < n_list && M.list_parts[tid] != 0 && M.list_part[tid] < 0) arrive(tid, false);
+    for (int e = 0; e < M.n_order; ++e) {
+        const int k = M.order[e];
+        const int g = M.list_g[k], ph = M.list_step[k], my_part = M.list_part[k], n_parts = M.list_parts[k];
+        long long my_deadline = deadline;
+        if (M.list_share[k] > 0 && deadline >= 0) {
+            const long long t0_ = (long long)__builtin_readcyclecounter();     // thread 0's clock for everybody
+            const long long t = ((long long)G_::bcast((int)(t0_ >> 32), tid, sm) << 32) | (unsigned)G_::bcast((int)t0_, tid, sm);
+            my_deadline = t >= deadline ? deadline : t + (deadline - t) / M.list_share[k];
         }
         const long long p0 = my_part < 0 ? 0 : my_part, p1 = my_part < 0 ? 0 : my_part + 1;      // share = [x * p0 / n_parts, x * p1 / n_parts)
         const GP P = game_ptrs(S, g);
@@ -1731,14 +1918,16 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         int32_t* queue = S.gc_queue + (size_t)g * N;
         int32_t* part = S.gc_part + (size_t)g * TM_GC_PART_DW;
         bool leftover = false;
-        if (ph == GCP_INIT) {
-            uint4* nt4 = reinterpret_cast<uint4*>(P.ntab());
-            uint4* ot4 = reinterpret_cast<uint4*>(P.otab());
-            const uint4 z4 = make_uint4(0, 0, 0, 0);
-            const long long n4 = S.table_cap / 2;
-            const int lo = (int)(n4 * p0 / n_parts), hi = (int)(n4 * p1 / n_parts);
-            for (int i = lo + tid; i < hi; i += T) { nt4[i] = z4; ot4[i] = z4; }
-            if (my_part == g % n_parts) {
+        if (ph == GCP_INIT || ph == GC_SPEC_REQ || ph == GC_REQ_SPEC) {
+            if (ph != GC_SPEC_REQ) {          // the tables are cleared once the game has stopped (it looks things up in them)
+                uint4* nt4 = reinterpret_cast<uint4*>(P.ntab());
+                uint4* ot4 = reinterpret_cast<uint4*>(P.otab());
+                const uint4 z4 = make_uint4(0, 0, 0, 0);
+                const long long n4 = S.table_cap / 2;
+                const int lo = (int)(n4 * p0 / n_parts), hi = (int)(n4 * p1 / n_parts);
+                for (int i = lo + tid; i < hi; i += T) { nt4[i] = z4; ot4[i] = z4; }
+            }
+            if (ph != GC_REQ_SPEC && my_part == g % n_parts) {      // (after a speculative marking the bitmaps and the queue stand)
                 for (size_t i = tid; i < 2 * bm_bytes / 4; i += T) nmw[i] = 0;      // both bitmaps
                 __syncthreads();
                 // breadth-first marking; index 0 is followed like any other child (core.h:41-45), so it stays occupied
@@ -1867,7 +2056,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
             // zeroes at GC, agents/agent.py:227-244; nothing reads a free slot in between).  Of a freed observation only
             // the statistics are cleared (16 B): a visit count of 0 keeps a slot that stays free from being harvested again.
             const int lo = (int)((long long)n_words * p0 / n_parts), hi = (int)((long long)n_words * p1 / n_parts);
-            const int low_obs = gs[TM_GS_LOW_OBS];
+            const int low_obs = gs[TM_GS_LOW_OBS], low_node = gs[TM_GS_LOW_NODE];
             int nbase = 0, obase = 0, kbase = harvest ? S.replay_count[g] : 0;      // (the count is updated by the step's last workgroup)
             for (int b = 0; b < my_part; ++b) { nbase += part[3 * b]; obase += part[3 * b + 1]; kbase += part[3 * b + 2]; }
             for (int wbase = lo; wbase < hi; wbase += T) {
@@ -1877,7 +2066,19 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                 const uint32_t fr = (wi < hi) ? (~nmw[wi] & valid) : 0u;
                 int total;
                 int pos = nbase + G_::exscan(__popc(fr), tid, sm, total);
-                for (uint32_t bits = fr; bits; bits &= bits - 1) P.fnode()[pos++] = wi * 32 + (__ffs(bits) - 1);
+                for (uint32_t bits = fr; bits; bits &= bits - 1) {
+                    const int i = wi * 32 + (__ffs(bits) - 1);
+                    P.fnode()[pos++] = i;
+                    // A free slot holds no child indices and no observation: a speculative marking may visit a node that the
+                    // game is creating in the same launch (it finds it in its parent's child row) before the node's own
+                    // initialisation is visible - it must not follow what the slot held in its previous life.
+                    if (i >= low_node) {
+                        const uint4 z4 = make_uint4(0, 0, 0, 0);
+                        uint4* kd = reinterpret_cast<uint4*>(P.kids() + (size_t)i * TM_KIDS_DW);
+                        kd[0] = z4; kd[1] = z4;
+                        reinterpret_cast<uint4*>(P.rec() + (size_t)i * TM_REC_DW)[7] = z4;
+                    }
+                }
                 nbase += total;
                 const uint32_t ofr = (wi < hi) ? (~omw[wi] & valid) : 0u;
                 int ototal;
@@ -1977,48 +2178,12 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                 }
             }
         }
-        // ---- arrive; the last workgroup moves the game on ----
+        // ---- arrive ----
         __syncthreads();
 #ifdef TM_GC_TIMING   /* diagnostic build: cycles/16 part 0 spent in each step of this game's last collection -> control words 48 + step */
         if (tid == 0 && my_part == 0) gs[48 + ph] = (ph == GCP_MARK ? gs[48 + ph] : 0) + (int)(((long long)__builtin_readcyclecounter() - t_step0) >> 4);
 #endif
-        if (tid == 0) {
-            bool any_left = false;
-            if (gc_arrive(gs, n_gc, leftover, any_left)) {
-                if (ph == GCP_INIT) {
-                    atomicExch(&gs[TM_GS_GC_TAIL], 1);
-                    atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF);
-                    gs[TM_GS_GC_TAIL0] = 1;
-                    gs[TM_GS_GC_HEAD0] = 0;
-                    gs[TM_GS_GC_PHASE] = GCP_MARK;
-                } else if (ph == GCP_MARK) {
-                    const int tl = atomicAdd(&gs[TM_GS_GC_TAIL], 0);
-                    gs[TM_GS_GC_TAIL0] = tl;
-                    gs[TM_GS_GC_HEAD0] = min(tl, atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF));
-                    if (!any_left) gs[TM_GS_GC_PHASE] = GCP_COUNT;
-                } else if (ph == GCP_COUNT) {
-                    gs[TM_GS_GC_PHASE] = GCP_WRITE;
-                } else if (ph == GCP_WRITE) {
-                    // the totals, from the counts of the launch before (nothing is exchanged inside a launch)
-                    int nf = 0, of = 0, kf = 0;
-                    for (int b = 0; b < n_b; ++b) { nf += part[3 * b]; of += part[3 * b + 1]; kf += part[3 * b + 2]; }
-                    gs[TM_GS_NFREE_NODE] = nf;
-                    gs[TM_GS_NFREE_OBS] = of;
-                    if (harvest) {
-                        const int m0 = S.replay_count[g];
-                        if (m0 + kf > S.replay_cap) gs[TM_GS_N_DROPPED] += m0 + kf - S.replay_cap;   // never silently (the reference keeps all up to memory_size)
-                        S.replay_count[g] = min(S.replay_cap, m0 + kf);
-                    }
-                    gs[TM_GS_GC_PHASE] = GCP_NODES;
-                } else if (ph == GCP_NODES) {
-                    gs[TM_GS_GC_PHASE] = GCP_OBS;
-                } else {
-                    gs[TM_GS_N_GC] += 1;
-                    gs[TM_GS_CYC_TAIL + 1] = gs[TM_GS_GC_TAIL0];      // reachable nodes at the last GC
-                    gs[TM_GS_GC_PHASE] = (seq << 4) | GC_DONE;
-                }
-            }
-        }
+        if (tid == 0) arrive(k, leftover);
         __syncthreads();
     }
 }
@@ -2048,15 +2213,19 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     int32_t* gs = P.gs();
     // The game's control block (64 words) in one coalesced load: word i in lane i, read with v_readlane.  A word is read
     // from the snapshot only before this launch writes it (the halves below write each word once, from lane 0).
-    const int gsv = gs[lane];
-    const int gc_req_word = (int)(((unsigned)flags >> 8) << 4) | GC_REQ;
+    int gsv = gs[lane];
+    int gc_req_word = (int)(((unsigned)flags >> 8) << 4) | GC_REQ;
     {
         // a collection requested, in progress, or completed in THIS launch: the game does not simulate (what a collector
-        // workgroup of this launch writes is not ordered with this wave's reads); completed in an earlier launch: resume
-        const int gcw = GSV(gsv, TM_GS_GC_PHASE);
-        if (gcw != 0) {
-            if ((gcw & 15) != GC_DONE || (gcw >> 4) == (int)((unsigned)flags >> 8)) return;
+        // workgroup of this launch writes is not ordered with this wave's reads); completed in an earlier launch: resume;
+        // a speculative marking (GC_SPEC_*): the game simulates, with the write barrier once the marking is under way
+        const int gcw = GSV(gsv, TM_GS_GC_PHASE), gph = gcw & 15;
+        if (gph == GC_SPEC_MARK) gc_req_word = (gc_req_word & ~15) | GC_REQ_SPEC;
+        else if (gph == GC_SPEC_REQ) gc_req_word = (gc_req_word & ~15) | GC_REQ_OVER;
+        else if (gcw != 0) {
+            if (gph != GC_DONE || (gcw >> 4) == (int)((unsigned)flags >> 8)) return;
             if (lane == 0) gs[TM_GS_GC_PHASE] = 0;
+            gsv = lane == TM_GS_GC_PHASE ? 0 : gsv;       // (the snapshot's phase word is what the finish stage tests)
         }
     }
     const int pend = GSV(gsv, TM_GS_PENDING);
@@ -2100,7 +2269,7 @@ __global__ void k_sims_remaining(tm_store S, int32_t* out) {
     if (g < S.n_games) {
         const int32_t* gs = S.gs + (size_t)g * TM_GS_DW;
         const int ph = gs[TM_GS_GC_PHASE] & 15;
-        col = (ph != 0 && ph != GC_DONE) ? 1 : 0;
+        col = (ph != 0 && ph != GC_DONE && ph != GC_SPEC_REQ && ph != GC_SPEC_MARK) ? 1 : 0;
         r = (gs[TM_GS_SIM_TARGET] - gs[TM_GS_SIM_STARTED]) + (gs[TM_GS_PENDING] != 0 ? 1 : 0) + col;
     }
     for (int d = 32; d >= 1; d >>= 1) { r = max(r, __shfl_xor(r, d, 64)); col += __shfl_xor(col, d, 64); }
@@ -2116,6 +2285,7 @@ __global__ __launch_bounds__(64 * WPB) void k_update_root(tm_store S) {
     GP P = game_ptrs(S, g);
     WaveLds& L = lds[w];
     if (lane < GAME_DW) L.slots[0][lane] = S.env_game[(size_t)g * GAME_DW + lane];
+    gc_drop_speculative(P, lane);      // the root moves: a speculative marking's marks would be stale
     wave_sync();
     int idx, o;
     wave_new_nodes(S, P, L, g, 1, lane, idx, o);
@@ -2145,6 +2315,7 @@ __global__ __launch_bounds__(64 * WPB) void k_tree_node(tm_store S, const uint32
     GP P = game_ptrs(S, g);
     WaveLds& L = lds[w];
     if (lane < GAME_DW) L.slots[0][lane] = games[(size_t)g * GAME_DW + lane];
+    gc_drop_speculative(P, lane);      // the tree changes outside a simulation launch: no barrier watches it
     wave_sync();
     int idx, o;
     wave_new_nodes(S, P, L, g, 1, lane, idx, o);

@@ -55,7 +55,7 @@ class TreeStore:
 
     def __init__(self, n_games, max_nodes=100000, kind=KIND_VALUESIM, env_args=((20, 10), 1, 0, 0), gamma=0.999,
                  low=1, eval_slots=None, max_trace=1024, nq_size=1 << 20, online=False, min_visits_to_store=10,
-                 replay_cap=0, gc_slice_cycles=150000, dist_bins=50, dist_range=(0.0, 5000.0), device="cuda"):
+                 replay_cap=0, gc_slice_cycles=150000, gc_spec_nodes=None, dist_bins=50, dist_range=(0.0, 5000.0), device="cuda"):
         if not torch.cuda.is_available():
             raise RuntimeError("tetris_mcts_amd needs a ROCm GPU (gfx950); there is no CPU path")
         shape, app, scoring, randomizer = env_args[0], env_args[1], env_args[2], env_args[3]
@@ -99,6 +99,8 @@ class TreeStore:
         s.app, s.scoring, s.randomizer = int(app), int(scoring), int(randomizer)
         s.low, s.kind, s.min_visits_to_store, s.online, s.replay_cap = int(low), int(kind), int(min_visits_to_store), int(bool(online)), int(replay_cap)
         s.gc_slice_cycles = int(gc_slice_cycles)
+        # speculative marking (tree.hip GC_SPEC_*) starts when a game has fewer free nodes than this
+        s.gc_spec_nodes = int(min(512, self.max_nodes // 8) if gc_spec_nodes is None else gc_spec_nodes)
         s.gamma = float(gamma)
         for name, typ in _lib.TmStore._fields_[16:]:
             if typ is C.c_void_p:
