@@ -72,7 +72,12 @@ enum {
     TM_GS_SIM_TARGET = 40, TM_GS_SIM_STARTED,
     TM_GS_CYC_VERIFY,    /* shader cycles of the last walk's parallel prefix verification (part of TM_GS_CYC_SELECT) */
     TM_GS_N_WALK_MISS,   /* tree levels at which the walk descended into another child than the predicted one (all simulations) */
-    TM_GS_POOL_FULL      /* the reachable tree fills the pool (TM_ERR_POOL): no collection is attempted until the root moves */
+    TM_GS_POOL_FULL,     /* the reachable tree fills the pool (TM_ERR_POOL): no collection is attempted until the root moves */
+    TM_GS_GC_IN_MOVE,    /* a collection has completed since the root last moved: until it moves again nothing becomes unreachable
+                            (the search only adds links), so the next exhaustion is counted as the reference's collection that
+                            frees nothing (agents/agent.py:96-97) and goes straight to TM_GS_POOL_FULL */
+    TM_GS_GC_REQ_AT      /* the launch in which the game asked for the collection it is waiting for (the waiting games' steps that
+                            do not all fit a launch are served oldest request first) */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */

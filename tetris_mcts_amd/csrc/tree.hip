@@ -317,7 +317,11 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     int nfree = has_gsv ? GSV(gsv, TM_GS_NFREE_NODE) : P.gs()[TM_GS_NFREE_NODE];
     if (__any(full)) { if (lane == 0) atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_TABLE); }
     if (cnt > nfree) {
-        const bool no_more_gc = has_gsv && (GSV(gsv, TM_GS_GC_RETRY) != 0 || GSV(gsv, TM_GS_POOL_FULL) != 0);
+        // (a collection that completed earlier in this move - TM_GS_GC_IN_MOVE - has left nothing to reclaim: the search only
+        // adds links below the root, so what was reachable then is reachable now and everything allocated since is linked.
+        // The reference collects again and frees nothing, agents/agent.py:96-97; counted, not done.)
+        const bool futile = has_gsv && GSV(gsv, TM_GS_GC_IN_MOVE) != 0 && GSV(gsv, TM_GS_GC_RETRY) == 0 && GSV(gsv, TM_GS_POOL_FULL) == 0;
+        const bool no_more_gc = has_gsv && (GSV(gsv, TM_GS_GC_RETRY) != 0 || GSV(gsv, TM_GS_POOL_FULL) != 0 || futile);
         if (!no_more_gc) {
             // Pool exhausted: the reference reclaims unreachable nodes at exactly this pop
             // (agents/agent.py:96-97).  Candidates before the exhausting one are inserted first, exactly as
@@ -335,7 +339,10 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         isnew = isnew && __popcll(need & ((1ull << lane) - 1ull)) < nfree;
         need = __ballot(isnew);
         cnt = __popcll(need);
-        if (lane == 0) { atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_POOL); P.gs()[TM_GS_POOL_FULL] = 1; }
+        if (lane == 0) {
+            atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_POOL); P.gs()[TM_GS_POOL_FULL] = 1;
+            if (futile) P.gs()[TM_GS_N_GC] = GSV(gsv, TM_GS_N_GC) + 1;
+        }
     }
     int idx = found;
     {
@@ -500,7 +507,11 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
             if (i1 < 0) {
                 if (!P.gs()[TM_GS_GC_RETRY] && !P.gs()[TM_GS_POOL_FULL]) {
                     if (lane < GAME_DW) L.slots[0][lane] = keep;
-                    if (lane == 0) { atomicExch(&P.gs()[TM_GS_GC_PHASE], gc_req_word); P.gs()[TM_GS_GC_RETRY] = 1; }
+                    if (lane == 0) {
+                        P.gs()[TM_GS_GC_REQ_AT] = gc_req_word >> 4;
+                        atomicExch(&P.gs()[TM_GS_GC_PHASE], gc_req_word);
+                        P.gs()[TM_GS_GC_RETRY] = 1;
+                    }
                     wave_sync();
                     return false;
                 }
@@ -820,10 +831,10 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
         gs[TM_GS_K_EVAL] = k_eval;
         gs[TM_GS_N_EVAL] = GSV(gsv, TM_GS_N_EVAL) + k_eval;
         // nearly out of nodes: have the tree marked while the game goes on (GC_SPEC_*), unless a collection could not help
-        // ... and only if the pool will run dry in THIS move (six nodes a simulation): update_root drops the marks
+        // ... and only if the pool can run dry in THIS move (seven nodes a simulation at most): update_root drops the marks
         if (S.gc_spec_nodes > 0 && GSV(gsv, TM_GS_GC_PHASE) == 0 && !leaf_end && !GSV(gsv, TM_GS_POOL_FULL) && !gs[TM_GS_POOL_FULL]) {
             const int nf = gs[TM_GS_NFREE_NODE], sims_left = GSV(gsv, TM_GS_SIM_TARGET) - GSV(gsv, TM_GS_SIM_STARTED);
-            if (nf < S.gc_spec_nodes && nf < 6 * sims_left) gs[TM_GS_GC_PHASE] = (gc_req_word & ~15) | GC_SPEC_REQ;
+            if (nf < S.gc_spec_nodes && nf < 7 * sims_left) gs[TM_GS_GC_PHASE] = (gc_req_word & ~15) | GC_SPEC_REQ;
         }
     }
 }
@@ -1646,6 +1657,7 @@ __device__ __forceinline__ void gc_drop_speculative(const GP& P, int lane) {
     const int ph = P.gs()[TM_GS_GC_PHASE] & 15;
     wave_sync();
     if (lane == 0 && (ph == GC_SPEC_REQ || ph == GC_SPEC_MARK)) P.gs()[TM_GS_GC_PHASE] = 0;
+    if (lane == 0) P.gs()[TM_GS_GC_IN_MOVE] = 0;      // (and what a collection left behind no longer says what is reachable)
     wave_sync();
 }
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, int lane) {
@@ -1676,7 +1688,7 @@ __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, i
 // ---------------------------------------------------------------------------------------------------
 constexpr int GCP_INIT = GC_REQ, GCP_MARK = 2, GCP_COUNT = 3, GCP_WRITE = 4, GCP_NODES = 5, GCP_OBS = 6;
 constexpr int GC_LIST_MAX = 256, GC_LIST_WAIT = 64;     // collecting games looked after per launch (the others wait): all, and those that are waiting for their collection
-constexpr int GC_COST_MAX = 6;       // per launch: cost units of the steps whose shares are done without looking at the clock
+constexpr int GC_COST_MAX = 12;      // per launch: cost units of the steps whose shares are done without looking at the clock
                                      // (init 1, count 1, write 2, nodes 5, observations 5: about 5 microseconds a unit)
 constexpr int GC_RING = 32;          // chunks of own discoveries a workgroup remembers while marking
 struct GcLds {
@@ -1686,6 +1698,7 @@ struct GcLds {
     int list_step[GC_LIST_MAX];                         // the launch's plan: the step performed for the game,
     short list_part[GC_LIST_MAX], list_parts[GC_LIST_MAX], list_share[GC_LIST_MAX];     // this workgroup's share (part of parts; parts 0: not in this launch)
     short order[GC_LIST_MAX]; int n_order;              // the games this workgroup works on, in order
+    int age[GC_LIST_WAIT]; short by_age[GC_LIST_WAIT];  // the waiting games: launches since the request, and sorted by that
     int ring_start[GC_RING], ring_cnt[GC_RING];
 };
 
@@ -1779,8 +1792,8 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
     const bool harvest = S.online && S.replay_cap > 0;
     // THE LAUNCH'S PLAN (every workgroup derives the same one: the control words it reads were written in earlier launches,
     // or are written in this one only after every workgroup has arrived for the game).
-    // The bounded steps first, as many as fit the launch's cost allowance, starting at a game that rotates with the launch
-    // number (nobody waits behind the low indices for ever); then the marking.  It is a breadth-first walk whose depth,
+    // The bounded steps first, as many as fit the launch's cost allowance - those of the waiting games oldest request first,
+    // then the speculative markings' starting at a game that rotates with the launch number; then the marking.  It is a breadth-first walk whose depth,
     // not its size, sets its duration (a round trip per level, a hundred levels and more), so the games that are marking
     // do not share the time but the WORKGROUPS: game j of the n_mark marking games is looked after by the marking
     // workgroups cm with cm % n_mark == j.  Workgroups [0, n_b) do the bounded steps, [n_b, n_gc) the marking (a lone
@@ -1796,6 +1809,14 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         int step = ph == GC_REQ_OVER ? GCP_INIT : ph;   // the step this launch performs for the game
         if (ph == GC_SPEC_MARK) step = gsk[TM_GS_GC_HEAD0] < gsk[TM_GS_GC_TAIL0] ? GCP_MARK : GC_IDLE;
         M.list_step[tid] = step;
+        if (tid < n_wait) M.age[tid] = (seq - gsk[TM_GS_GC_REQ_AT]) & 0x7FFFF;      // launches since the game asked (the launch number has 19 bits)
+    }
+    __syncthreads();
+    if (tid < n_wait) {        // the waiting games, oldest request first
+        const int mine = M.age[tid];
+        int rank = 0;
+        for (int j = 0; j < n_wait; ++j) { const int other = M.age[j]; rank += (other > mine || (other == mine && j < tid)) ? 1 : 0; }
+        M.by_age[rank] = (short)tid;
     }
     __syncthreads();
     if (tid == 0) {
@@ -1812,7 +1833,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         for (int pass = 0; pass < 4; ++pass) {            // bounded steps of the waiting games, of the others; the markings likewise
             const int cls = pass & 1, first = cls ? n_wait : 0, n = cls ? n_spec : n_wait;
             for (int i = 0; i < n; ++i) {
-                const int k = first + (i + seq) % n;
+                const int k = pass == 0 ? M.by_age[i] : first + (i + seq) % n;
                 const int step = M.list_step[k];
                 if ((pass < 2) == (step == GCP_MARK)) continue;
                 int my_part = -1, n_parts = 1, share = 0;
@@ -1893,6 +1914,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
             gs[TM_GS_GC_PHASE] = GCP_OBS;
         } else {      // GCP_OBS
             gs[TM_GS_N_GC] += 1;
+            gs[TM_GS_GC_IN_MOVE] = 1;
             gs[TM_GS_CYC_TAIL + 1] = gs[TM_GS_GC_TAIL0];      // reachable nodes at the last GC
             gs[TM_GS_GC_PHASE] = (seq << 4) | GC_DONE;
         }
@@ -2296,7 +2318,7 @@ __global__ __launch_bounds__(64 * WPB) void k_update_root(tm_store S) {
     }
     if (lane == 0) {
         P.gs()[TM_GS_ROOT] = idx;
-        P.gs()[TM_GS_POOL_FULL] = 0;        // a new root: the old root's siblings are garbage now
+        P.gs()[TM_GS_POOL_FULL] = 0;        // a new root: the old root's siblings are garbage now (TM_GS_GC_IN_MOVE was cleared above)
         if ((L.slots[0][11] >> 8) & 1u) P.gs()[TM_GS_EPISODE] += 1;
     }
 }
@@ -2346,7 +2368,7 @@ __global__ __launch_bounds__(64 * WPB) void k_tree_gc(tm_store S, const uint8_t*
     const int g = blockIdx.x;
     if (mask && !mask[g]) return;
     GP P = game_ptrs(S, g);
-    if (threadIdx.x == 0) P.gs()[TM_GS_GC_PHASE] = GC_REQ;
+    if (threadIdx.x == 0) { P.gs()[TM_GS_GC_PHASE] = GC_REQ; P.gs()[TM_GS_GC_IN_MOVE] = 0; }      // (a speculative marking is simply overwritten)
     __syncthreads();
     gc_collect<64 * WPB>(S, P, g, (int)threadIdx.x, sm);
 }
@@ -2454,6 +2476,7 @@ __global__ void k_pool_reset(tm_store S, const uint8_t* mask) {
         P.gs()[TM_GS_GC_PHASE] = 0;
         P.gs()[TM_GS_GC_RETRY] = 0;
         P.gs()[TM_GS_POOL_FULL] = 0;
+        P.gs()[TM_GS_GC_IN_MOVE] = 0;
         P.gs()[TM_GS_GC_ARRIVE] = 0;
         P.gs()[TM_GS_SIM_STARTED] = P.gs()[TM_GS_SIM_TARGET];
         P.gs()[TM_GS_ERR] &= ~TM_ERR_POOL;

@@ -15,7 +15,7 @@ KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA, 
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18, MAX_TRACE=19, N_DROPPED=25,
           CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_SLICES=38,
-          SIM_TARGET=40, SIM_STARTED=41, CYC_VERIFY=42, FIRST_MISS=28, PREFIX_SUM=29, N_WALK_MISS=43, POOL_FULL=44)
+          SIM_TARGET=40, SIM_STARTED=41, CYC_VERIFY=42, FIRST_MISS=28, PREFIX_SUM=29, N_WALK_MISS=43, POOL_FULL=44, GC_IN_MOVE=45, GC_REQ_AT=46)
 
 _nq_cache = {}
 
@@ -100,7 +100,7 @@ class TreeStore:
         s.low, s.kind, s.min_visits_to_store, s.online, s.replay_cap = int(low), int(kind), int(min_visits_to_store), int(bool(online)), int(replay_cap)
         s.gc_slice_cycles = int(gc_slice_cycles)
         # speculative marking (tree.hip GC_SPEC_*) starts when a game has fewer free nodes than this
-        s.gc_spec_nodes = int(min(512, self.max_nodes // 8) if gc_spec_nodes is None else gc_spec_nodes)
+        s.gc_spec_nodes = int(min(256, self.max_nodes // 8) if gc_spec_nodes is None else gc_spec_nodes)
         s.gamma = float(gamma)
         for name, typ in _lib.TmStore._fields_[16:]:
             if typ is C.c_void_p:
