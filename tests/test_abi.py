@@ -144,3 +144,33 @@ def test_oracle_engine_is_loaded_by_path_whatever_pyTetris_means(oracle):
     finally:
         sys.path.remove(ROOT)
         sys.modules.pop("pyTetris", None)
+
+
+def test_control_block_words_match_the_header():
+    """store.GS (the Python names of the per-game control words) against the enum of include/tetris_mcts_hip.h."""
+    import importlib
+    hdr = open(os.path.join(ROOT, "include", "tetris_mcts_hip.h")).read()
+    body = hdr[hdr.index("enum {", hdr.index("per-game control block (int32 words)")):]
+    body = re.sub(r"/\*.*?\*/", "", body[:body.index("};")], flags=re.S)
+    words, nxt = {}, 0
+    for item in body[body.index("{") + 1:].split(","):
+        item = item.strip()
+        if not item:
+            continue
+        m = re.match(r"(TM_GS_[A-Z0-9_]+)(?:\s*=\s*(\d+))?$", item)
+        assert m, item
+        nxt = int(m.group(2)) if m.group(2) else nxt
+        words[m.group(1)[6:]] = nxt
+        nxt += 1
+    assert max(words.values()) < 64 and len(set(words.values())) == len(words)     # TM_GS_DW, no word twice
+    spec = importlib.util.spec_from_file_location("tm_store_py", os.path.join(ROOT, "tetris_mcts_amd", "store.py"))
+    src = open(spec.origin).read()
+    gs = eval("dict(" + src[src.index("GS = dict(") + 10:src.index(")", src.index("GS = dict("))] + ")")
+    alias = {"CYC_GC16": ("CYC_TAIL", 0), "GC_REACHABLE": ("CYC_TAIL", 1)}
+    for name, idx in gs.items():
+        base, off = alias.get(name, (name, 0))
+        assert words[base] + off == idx, (name, idx, words.get(base))
+    for name in ("GC_PHASE", "GC_IN_MOVE", "GC_REQ_AT", "POOL_FULL", "SIM_TARGET", "SIM_STARTED"):
+        assert name in gs
+    L = _lib()
+    assert L.TmStore.gc_spec_nodes.offset == L.TmStore.dist_bins.offset + 4
