@@ -24,10 +24,10 @@ def _make(name, G, sims, max_nodes, seed, evaluator=None, model=None, **kw):
 
 
 def _compare_run(oracle, name, G, sims, max_nodes, seed, moves, evaluator, params=None, model=None, env_args=None,
-                 check_tree_every=0):
+                 check_tree_every=0, **agent_kw):
     env_args = env_args or ((20, 10), 1, 0, 0)
     game, agent = _make(name, G, sims, max_nodes, seed, evaluator=hash_eval_torch if evaluator == "hash" else None,
-                        model=model, env_args=env_args)
+                        model=model, env_args=env_args, **agent_kw)
     og = [oracle.Game(env_args[1], env_args[2], env_args[3], seed + g) for g in range(G)]
     oa = [oracle.Agent(KIND[name], max_nodes=max_nodes, app=env_args[1], scoring=env_args[2], randomizer=env_args[3],
                        evaluator=evaluator, params=params) for _ in range(G)]
@@ -85,13 +85,27 @@ def test_valuesimlp_hash_eval_with_gc(oracle):
     assert gcs >= 1
 
 
-def test_many_games_collecting_at_once(oracle):
+@pytest.mark.parametrize("gc_spec_nodes", [None, 0, 2000])
+def test_many_games_collecting_at_once(oracle, gc_spec_nodes):
     """The collector workgroups under load: 96 games with 3000-node pools, every game collects every few dozen moves and many
-    of them at the same time (shared marking workgroups, rotating order, bounded steps queueing for their cost allowance),
-    every action and every root statistic against the games' own oracles, whole trees at the end."""
+    of them at the same time (shared marking workgroups, bounded steps queueing for their cost allowance, oldest request
+    first), every action and every root statistic against the games' own oracles, whole trees every 30 moves.  With the
+    default speculative marking (a game with fewer than 256 free nodes is marked while it simulates), without it (0), and
+    with every game that can run dry in its move being marked (2000: dozens of speculative markings at a time, requests
+    overtaken by the pool running dry)."""
     gcs = _compare_run(oracle, "ValueSim", G=96, sims=30, max_nodes=3000, seed=77, moves=150, evaluator="hash",
-                       check_tree_every=30)
+                       check_tree_every=30, gc_spec_nodes=gc_spec_nodes)
     assert gcs >= 300
+
+
+@pytest.mark.parametrize("gc_spec_nodes", [None, 2000])
+def test_more_collections_at_once_than_the_collectors_list(oracle, gc_spec_nodes):
+    """640 games with equal 2000-node pools run dry within a few moves of each other: hundreds of collections under way at
+    the same time - more than the collector workgroups look after per launch (64 waiting games, 192 speculative markings:
+    the others wait their turn), more marking games than marking workgroups (their time is shared)."""
+    gcs = _compare_run(oracle, "ValueSim", G=640, sims=20, max_nodes=2000, seed=4242, moves=64, evaluator="hash",
+                       check_tree_every=32, gc_spec_nodes=gc_spec_nodes)
+    assert gcs >= 900
 
 
 def test_valuesim_app2_uniform_randomizer(oracle):
