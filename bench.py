@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STATE = 3803136            # conv1 82,944 + conv2 1,769,472 + conv3 1,032,192 + fc1 917,504 + fc_out 1,024
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic*.json")      # one file per profiled command line (workload_key)
+PMC_FILE = os.path.join("profiles", "r0[34]_pmc_traffic*.json")      # one file per profiled command line (workload_key)
 
 
 def pmc_traffic(kernels, workload_key, fetch_scale=1.0):
@@ -124,7 +124,7 @@ def main():
     if is_dist:
         # BASELINE configs[4]: the distributional head (model/model_distributional.py Net, 50 atoms over [0, 5000)), random init
         from tetris_mcts_amd.model_distributional import Model_Dist
-        model = Model_Dist(atoms=50, seed=0)
+        model = Model_Dist(atoms=50, seed=0, backend=args.backend)
         assert not args.online, "the distributional agent has no online leg (DESIGN.md section 8)"
     else:
         model = Model_VV(backend=args.backend, seed=0)  # model_vv.Net() under torch.manual_seed(0) (random init)
@@ -137,6 +137,7 @@ def main():
     torch.cuda.synchronize()
     S = agent.store
     dev = S.device
+    py_loop = agent.search_model() is False     # the launch loop runs in Python (an evaluator that is not a HIP net)
     K = S.eval_slots
     NS = agent.n_sub
     episodes, lines = 0, 0
@@ -185,7 +186,7 @@ def main():
         episodes, lines = 0, 0
         torch.cuda.synchronize()
         S.search_stats(NS, EV_EVERY, reset=True)
-        if is_dist:
+        if py_loop:
             agent.loop_stats(reset=True)
         if world > 1:
             dist.barrier()
@@ -200,7 +201,7 @@ def main():
         elapsed = time.perf_counter() - t0
         c1 = counters()
         ss = S.search_stats(NS, EV_EVERY, reset=False) or {}
-        if is_dist:      # the launch loop ran in Python (TreeAgent.mcts): its own sampled events
+        if py_loop:      # the launch loop ran in Python (TreeAgent.mcts): its own sampled events
             ss = agent.loop_stats(reset=True)
         err = int((S.errors() != 0).sum().item())
         d = {k: c1[k] - c0[k] for k in c0}
@@ -224,7 +225,7 @@ def main():
         time per simulation the two must add up to (the sampled intervals each carry the cost of their own event records,
         so their plain sum slightly exceeds the step)."""
         ss = r["ss"]
-        if is_dist and ss.get("timed"):      # Python-driven loop: the sampled intervals as they are
+        if py_loop and ss.get("timed"):      # Python-driven loop: the sampled intervals as they are
             nn_ev, tree_ev = ss["nn_ms_sum"] / ss["timed"], ss["tree_ms_sum"] / ss["timed"]
             return dict(nn_ms=nn_ev, tree_ms=tree_ev, nn_event_ms=nn_ev, tree_event_ms=tree_ev, per_sim_ms=nn_ev + tree_ev,
                         timed=int(ss["timed"]))
@@ -339,11 +340,13 @@ def main():
                  "sampled intervals %.4f / %.4f ms, each carrying its own event records); avg_launch_ms x %d simulations <= "
                  "ms_per_step by construction.  The rocprofv3 kernel trace of the same command is profiles/r03_kernel_stats_*.csv"
                  % (kf["per_sim_ms"], EV_EVERY, kf["nn_event_ms"], kf["tree_event_ms"], sims))
-        nn_roof = {"kernel": ("distributional head (model_distributional.Net on PyTorch-ROCm: MIOpen / rocBLAS kernels + the request render), per evaluation of %d leaves" if is_dist else "value net forward (k_vn_conv + k_vn_fc1 with the output layer folded in), per launch of %d request slots") % int(Gs * K),
+        nn_roof = {"kernel": (("distributional head (k_dn_conv + k_dn_fc: render, two convolutions, two linear layers and the softmax on the fp32 matrix cores), per launch of %d leaves"
+                               if args.backend == "hip" else "distributional head (model_distributional.Net on PyTorch-ROCm: MIOpen / rocBLAS kernels + the request render), per evaluation of %d leaves")
+                              if is_dist else "value net forward (k_vn_conv + k_vn_fc1 with the output layer folded in), per launch of %d request slots") % int(Gs * K),
                    "bound": "mfma", "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                    "frac": a_tf / PEAK_F32_MATRIX_TFLOPS,
-                   "traffic": pmc_traffic(["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1"], workload_key, 2.0)
-                   if (args.backend == "hip" and not is_dist) else None,
+                   "traffic": pmc_traffic(["tmcts_dn::k_dn_conv", "tmcts_dn::k_dn_fc"] if is_dist else ["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1"],
+                                          workload_key, 2.0) if args.backend == "hip" else None,
                    "traffic_note": note + "; FETCH_SIZE x2 (wide streams)",
                    "avg_launch_ms": nn_ms, "launches_timed": kf["timed"], "events_every": EV_EVERY, "timing_note": tnote}
         tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % int(Gs), "bound": "hbm",

@@ -40,6 +40,11 @@ extern "C" {
 #define TM_VALUENET_SCRATCH_MFMA 2064  /* floats of scratch per state, tm_valuenet_forward / _requests: ZERO-FILLED before the first call
                                           (the kernels keep a counter per 32 states in it and leave it zero) */
 #define TM_VALUENET_PREPARED 477184    /* floats: conv2 + conv3 + fc1 operand streams */
+#define TM_DISTNET_PARAMS(atoms) (279232 + 129 * (atoms))  /* floats: conv1.w[32][1][4][4] conv1.b[32] conv2.w[32][32][4][4] conv2.b[32]
+                                          fc1.w[128][2048] fc1.b[128] fc_v.w[atoms][128] fc_v.b[atoms] (model/model_distributional.py:33-42) */
+#define TM_DISTNET_PARAMS_50 285682    /* TM_DISTNET_PARAMS(50) */
+#define TM_DISTNET_PREPARED 278528     /* floats: conv2 + fc1 operand streams */
+#define TM_DISTNET_SCRATCH 2048        /* floats of scratch per state (conv2's output), tm_distnet_forward / _requests */
 
 /* per-game control block (int32 words) */
 enum {
@@ -206,7 +211,9 @@ int tm_store_slice(const tm_store *s, int first, int n, tm_store *out);
  * their own HIP streams so that one sub-batch's tree kernel runs under another's value-net kernels; results per game do
  * not depend on n_sub.  tm_search_run returns when all `sims` simulations of every game are complete (it issues the
  * catch-up launches of games that collected garbage, tm_sims_remaining).  vn_params == NULL: no evaluator launches
- * (TM_KIND_VANILLA).  vn_scratch: n_games * eval_slots * TM_VALUENET_SCRATCH_MFMA floats.  ev_every > 0: HIP events
+ * (TM_KIND_VANILLA).  The evaluator follows the store's kind: the value net (tm_valuenet_forward_requests; vn_scratch:
+ * n_games * eval_slots * TM_VALUENET_SCRATCH_MFMA floats, zero-filled) or, for TM_KIND_DIST, the distributional head
+ * (tm_distnet_forward_requests; vn_params / vn_prepared = its blobs, vn_scratch: n_games * TM_DISTNET_SCRATCH floats).  ev_every > 0: HIP events
  * around every ev_every-th simulation of sub-batch 0 (on the stream it runs on), read back by tm_search_stats:
  * out = {runs, tree launches, catch-up launches, timed samples, sum tree-kernel ms, sum value-net ms, n_sub}. */
 typedef struct tm_search tm_search;
@@ -280,6 +287,19 @@ int tm_valuenet_forward_requests(const float *params, const float *prepared, con
                                  void *stream);
 int tm_valuenet_forward_plain(const float *params, const int8_t *states, int n, float *v, float *var, float *scratch,
                               void *stream);
+
+/* distributional value head (model/model_distributional.py:18-57 `Net`, Model_Dist.inference :100-107), the leaf evaluator
+ * of TM_KIND_DIST: states int8 [n][200] (the 20 visible rows; the net's two extra rows on top are empty) -> softmax over
+ * `atoms` (<= 64) bins, dist[i * dist_stride + b].  params: TM_DISTNET_PARAMS(atoms) floats in PyTorch state_dict order and
+ * layouts; tm_distnet_prepare re-lays conv2 / fc1 into MFMA operand streams (after every weight change).  fp32 matrix cores,
+ * one k-ordered fma chain per pre-activation (oracle/distnet_oracle.c computes the same bits).  scratch: n x
+ * TM_DISTNET_SCRATCH floats, no initial contents required. */
+int tm_distnet_prepare(const float *params, float *prepared, void *stream);
+int tm_distnet_forward(const float *params, const float *prepared, const int8_t *states, int n, int atoms, float *dist,
+                       int dist_stride, float *scratch, void *stream);
+/* the tree engine's pending requests (TM_KIND_DIST: s->eval_obs[g] = the leaf NODE of game g, rendered from its packed game
+ * inside the first kernel) -> s->eval_dist[g][0 .. dist_bins); scratch: n_games x TM_DISTNET_SCRATCH floats */
+int tm_distnet_forward_requests(const float *params, const float *prepared, const tm_store *s, float *scratch, void *stream);
 
 const char *tm_version(void);
 /* sizeof(tm_store) and a few offsets, so a host mirror of the struct can be checked without a GPU */

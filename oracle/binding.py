@@ -90,6 +90,7 @@ def lib():
         L.orc_valuenet_forward.argtypes = [vp, vp, i32, vp, vp]
         L.orc_hash_eval.argtypes = [vp, vp, i32, vp, vp]
         L.orc_hash_dist.argtypes = [vp, vp, i32, i32, vp]
+        L.orc_distnet_forward.argtypes = [vp, vp, i32, i32, vp]
         L.orc_agent_set_dist.argtypes = [vp, i32, f64, f64, vp]
         L.orc_agent_node_stats.restype = L.orc_agent_node_dist.restype = vp
         L.orc_agent_node_stats.argtypes = L.orc_agent_node_dist.argtypes = [vp]
@@ -160,7 +161,12 @@ class Agent:
         if min_visits_to_store is None:
             min_visits_to_store = {0: 10, 1: 25}.get(kind, 40)
         self._keep = None
-        if evaluator == "hash" or kind == 6:
+        if kind == 6 and evaluator == "distnet":
+            # the distributional head (distnet_oracle.c); params: TM_DISTNET_PARAMS(dist_bins) floats, state_dict order
+            self._keep = np.ascontiguousarray(params, np.float32)
+            assert self._keep.size == 279232 + 129 * int(dist_bins)
+            fn, ctx = C.cast(L.orc_hash_eval, C.c_void_p), ptr(self._keep)
+        elif evaluator == "hash" or kind == 6:
             fn, ctx = C.cast(L.orc_hash_eval, C.c_void_p), None
         elif evaluator == "valuenet":
             self._keep = np.ascontiguousarray(params, np.float32)
@@ -183,6 +189,8 @@ class Agent:
             self.bins, self.vrange = int(dist_bins), (float(dist_vmin), float(dist_vmax))
             if evaluator == "hash":
                 dfn = C.cast(L.orc_hash_dist, C.c_void_p)
+            elif evaluator == "distnet":
+                dfn = C.cast(L.orc_distnet_eval, C.c_void_p)
             else:
                 def _dcb(_ctx, states, k, bins, out):
                     st = np.ctypeslib.as_array(C.cast(states, C.POINTER(C.c_int8)), (k, 20, 10))

@@ -6,7 +6,10 @@ launch loop (search.hip) with sub-batches on separate streams.
 Covered on purpose, with assertions that they really happened:
   * traces longer than 128 nodes (two flushes of the 64-entry LDS trace buffer, three chunks of the backup),
   * a garbage collection at the full 100 000-entry pool, by the collector workgroups, with the catch-up launches that follow,
-  * sampled games of a real 4096-game batch (results must not depend on the batch a game runs in).
+  * sampled games of a real 4096-game batch (results must not depend on the batch a game runs in),
+  * the steady state the second bench window is taken in: the same 4096-game batch played on to move 90, a thousand
+    collections by the collector workgroups under load (speculative marking, waiting lists, catch-up launches), games
+    chosen AFTER the run by what happened to them - incl. one whose reachable tree outgrew the pool.
 The oracle games run in parallel threads (liboracle releases the GIL)."""
 from concurrent.futures import ThreadPoolExecutor
 
@@ -128,5 +131,99 @@ def test_sampled_games_of_a_real_4096_game_batch(oracle, name, moves, n_sub):
     if name == "ValueSimLP":
         assert agent.store.eval_slots == 7 and agent.store.t["eval_obs"].numel() == 28672
         assert int(gs[:, 17].sum().item()) > 3 * int(gs[:, 7].sum().item())     # several evaluated states per expansion
+    del agent
+    torch.cuda.empty_cache()
+
+
+def test_steady_state_of_the_real_4096_game_batch(oracle):
+    """The regime of bench.py's steady-state window (moves 76-95): the benchmark's 4096 games x 500 sims x 100 000-node pools
+    played to move 90 through the native loop.  Every move's actions and root statistics of ALL games are recorded; the games
+    to check are picked afterwards - game 1 (collects at move 74), the games with the most collections, one that waited
+    longest for its collection, and one whose reachable tree outgrew the pool (the reference's MAX_NODES EXCEEDED state,
+    agent.py:96-97 / agent.cpp:227-231: compared up to the move the oracle reports the same exhaustion in, and the restart
+    must happen exactly there) - and replayed by their own oracles in threads: actions, statistics bytes, episode ends,
+    collection / expansion / simulation counters and the whole reachable tree."""
+    import torch
+    from tetris_mcts_amd import agents
+    from tetris_mcts_amd.pyTetris import Tetris
+    MOVES, SIMS, N, G = 90, 500, 100000, 4096
+    model, params = _bench_model()
+    env_args = ((20, 10), 1, 0, 0)
+    seeds = BASE_SEED + np.arange(G)
+    game = Tetris(*env_args, seed=seeds, n_games=G)
+    agent = agents.ValueSim(sims=SIMS, env=Tetris, env_args=env_args, n_games=G, max_nodes=N, model=model, online=False)
+    agent.update_root(game)
+    st = agent.store
+    acts = np.zeros((MOVES, G), np.int32)
+    stats = np.zeros((MOVES, G, 21), np.float32)
+    ends = np.zeros((MOVES, G), bool)
+    resets = np.zeros((MOVES, G), np.int32)          # TM_GS_N_POOL_RESET after the move's update_root
+    for m in range(MOVES):
+        acts[m] = np.atleast_1d(agent.play())
+        stats[m] = agent.get_stats().reshape(G, 21)
+        game.play(acts[m])
+        agent.update_root(game)
+        ends[m] = np.atleast_1d(game.end)
+        if ends[m].any():
+            game.reset("ended")
+            agent.update_root(game)
+        resets[m] = st.t["gs"][:, 18].cpu().numpy()
+    gs = st.t["gs"].cpu().numpy()
+    n_gc, n_reset = gs[:, 9], gs[:, 18]
+    assert int((gs[:, 6] & ~1).sum()) == 0                     # no error flag but the pool one
+    assert (gs[:, 8] == MOVES * SIMS).all()                    # every game ran every simulation (catch-up launches included)
+    total_gc = int(n_gc.sum())
+    ss = st.search_stats(1, 0)
+    print("collections", total_gc, "trees restarted", int(n_reset.sum()), "catch-up launches", ss["catchup_launches"],
+          "collector-only launches", ss["gc_launches"])
+    assert total_gc >= 1000, total_gc                          # the concurrent regime, not a collection here and there
+    assert ss["catchup_launches"] > 0
+    clean = n_reset == 0
+    order = np.argsort(-(n_gc * clean), kind="stable")
+    sample = [1] + [int(g) for g in order[:2] if g != 1]
+    slices_per_gc = np.where(n_gc > 0, gs[:, 38] / np.maximum(n_gc, 1), 0) * clean
+    slow = int(np.argmax(slices_per_gc))
+    if slow not in sample:
+        sample.append(slow)
+    full = np.nonzero(n_reset > 0)[0]
+    if len(full):
+        first_reset = (resets[:, full] > 0).argmax(0)
+        sample.append(int(full[np.argmin(first_reset)]))       # the earliest restart: most moves after it are not comparable anyway
+    assert clean[1] and n_gc[1] >= 1
+
+    def replay(g):
+        o = _OracleGame(oracle, 0, int(seeds[g]), params, N)
+        for m in range(MOVES):
+            a, s, e = o.move(SIMS)
+            if o.a.error:
+                return o, m                                    # the oracle's pool is exhausted in move m (MAX_NODES EXCEEDED)
+            assert a == acts[m, g], ("action", g, m, a, acts[m, g])
+            assert s.tobytes() == stats[m, g].tobytes(), ("stats", g, m, s, stats[m, g])
+            assert bool(e) == bool(ends[m, g]), ("end", g, m)
+        return o, MOVES
+
+    with ThreadPoolExecutor(max_workers=len(sample)) as pool:
+        res = list(pool.map(replay, sample))
+    for g, (o, upto) in zip(sample, res):
+        if n_reset[g] > 0:
+            # the tree was restarted at the update_root of the very move in which the reference runs out of nodes
+            assert upto < MOVES and o.a.error == 1, (g, upto)
+            assert resets[upto, g] >= 1 and (upto == 0 or resets[upto - 1, g] == 0), (g, upto, resets[:, g])
+            continue
+        assert upto == MOVES and o.a.error == 0
+        assert gs[g, 9] == o.a.n_gc and gs[g, 7] == o.a.n_expand and gs[g, 8] == o.a.n_sims, (g, gs[g, :10], o.a.n_gc)
+        assert gs[g, 19] == o.a.max_trace_len
+        dev = st.export_game(g)
+        ref = o.a.arrays()
+        mark = np.zeros(N, np.uint8)
+        oracle.lib().orc_get_all_childs(o.a.root, oracle.ptr(ref["child"]), N, oracle.ptr(mark))
+        occ = np.nonzero(mark)[0]
+        assert gs[g, 0] == o.a.root
+        for k in ("child", "score", "n_to_o"):
+            assert np.array_equal(dev[k][occ], ref[k][occ]), (k, g)
+        oo = np.unique(ref["n_to_o"][occ])
+        for k in ("visit", "value", "variance", "end_obs"):
+            assert dev[k][oo].tobytes() == ref[k][oo].tobytes(), (k, g)
+    assert sum(int(n_gc[g]) for g in sample if n_reset[g] == 0) >= 3
     del agent
     torch.cuda.empty_cache()

@@ -96,6 +96,168 @@ def test_dist_agent_matches_the_oracle_bit_for_bit(oracle, max_nodes, moves, sim
         assert n_gc > 0          # the small pool went through collections
 
 
+def _ref_net_params(golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "ref_distnet.npz"))
+    keys = ["seq__conv1__weight", "seq__conv1__bias", "seq__conv2__weight", "seq__conv2__bias", "seq__fc1__weight",
+            "seq__fc1__bias", "seq__fc_v__weight", "seq__fc_v__bias"]
+    return g, np.concatenate([g[k].ravel() for k in keys]).astype(np.float32)
+
+
+def test_hip_head_matches_the_oracle_bit_for_bit_and_the_reference_net(oracle, golden_dir):
+    """csrc/distnet.hip (k_dn_conv + k_dn_fc, fp32 matrix cores) vs oracle/distnet_oracle.c: the same bits on random boards
+    (a batch that is not a multiple of a tile, one state alone), and within 1e-6 relative of the reference's own Net on its
+    fixture (model/model_distributional.py:18-57 run on CPU, tests/golden/ref_distnet.npz)."""
+    import torch
+    from tetris_mcts_amd.model_distributional import Model_Dist
+    g, P = _ref_net_params(golden_dir)
+    mdl = Model_Dist(atoms=50, backend="hip")
+    mdl.set_flat_params(P)
+    x = g["x"]
+    assert (x[:, 0, :2] == 0).all()
+    st = np.ascontiguousarray(x[:, 0, 2:, :].reshape(16, 200).astype(np.int8))
+    y = mdl.inference_device(torch.from_numpy(st).cuda())[:, :50].cpu().numpy()
+    assert np.abs(y - g["y"]).max() <= 1e-6 * np.abs(g["y"]).max() and np.all(np.abs(y - g["y"]) <= 1e-6 * g["y"] + 1e-9)
+    assert np.array_equal(mdl.inference(x)[0], y)                      # the reference's signature ([B,1,22,10] floats)
+    rng = np.random.default_rng(5)
+    for n in (1, 16, 1003):
+        st = rng.integers(-1, 2, size=(n, 200)).astype(np.int8)
+        st[: n // 2, :100] = 0                                        # half of them with an empty upper half, like real boards
+        ref = np.zeros((n, 50), np.float32)
+        oracle.lib().orc_distnet_forward(oracle.ptr(P), oracle.ptr(st), n, 50, oracle.ptr(ref))
+        out = mdl.inference_device(torch.from_numpy(st).cuda())
+        assert out[:, :50].cpu().numpy().tobytes() == ref.tobytes(), n
+        assert float(out[:, 50:].abs().sum()) == 0.0
+    # other numbers of atoms go through the same kernels (padding rows of the last FC tile)
+    for atoms in (7, 64):
+        m2 = Model_Dist(atoms=atoms, backend="hip", seed=atoms)
+        P2 = m2.flat_params().cpu().numpy()
+        st = rng.integers(-1, 2, size=(40, 200)).astype(np.int8)
+        ref = np.zeros((40, atoms), np.float32)
+        oracle.lib().orc_distnet_forward(oracle.ptr(P2), oracle.ptr(st), 40, atoms, oracle.ptr(ref))
+        out = m2.inference_device(torch.from_numpy(st).cuda())[:, :atoms].cpu().numpy()
+        assert out.tobytes() == ref.tobytes(), atoms
+        tor = Model_Dist(atoms=atoms, backend="torch", seed=atoms).inference_device(torch.from_numpy(st).cuda())[:, :atoms].cpu().numpy()
+        assert np.allclose(out, tor, rtol=2e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("max_nodes,moves,sims", [(20000, 6, 150), (4000, 12, 150)])
+def test_dist_agent_with_the_hip_head_matches_the_oracle_bit_for_bit(oracle, max_nodes, moves, sims):
+    """DistValueSim as it is benchmarked - the distributional head as HIP kernels inside the native launch loop (search.hip),
+    requests rendered from the nodes' packed games - against oracle kind 6 with distnet_oracle.c as its evaluator: actions,
+    root statistics, every reachable node's statistics and distributions, through collections."""
+    import torch
+    from tetris_mcts_amd import agents
+    from tetris_mcts_amd.model_distributional import Model_Dist
+    from tetris_mcts_amd.pyTetris import Tetris
+    G = 8
+    env_args = ((20, 10), 1, 0, 0)
+    seeds = 777 + np.arange(G)
+    model = Model_Dist(atoms=50, seed=0, backend="hip")
+    P = model.flat_params().cpu().numpy()
+    game = Tetris(*env_args, seed=seeds, n_games=G)
+    agent = agents.DistValueSim(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=max_nodes, model=model)
+    assert agent.search_model() is model
+    agent.update_root(game)
+    og = [oracle.Game(seed=int(s)) for s in seeds]
+    oa = [oracle.Agent(6, max_nodes=max_nodes, low=5, evaluator="distnet", params=P) for _ in range(G)]
+    for g in range(G):
+        oa[g].update_root(og[g])
+    for m in range(moves):
+        act = np.atleast_1d(agent.play())
+        stats = agent.get_stats().reshape(G, 3, 7)
+        for g in range(G):
+            a = oa[g].play(sims)
+            assert a == act[g], ("action", m, g, a, act[g], oa[g].stats(), stats[g])
+            assert oa[g].stats().tobytes() == stats[g].tobytes(), ("stats", m, g, oa[g].stats(), stats[g])
+            og[g].play(a)
+            oa[g].update_root(og[g])
+        game.play(act)
+        agent.update_root(game)
+        ended = np.atleast_1d(game.end)
+        if ended.any():
+            game.reset("ended")
+            agent.update_root(game)
+            for g in np.nonzero(ended)[0]:
+                og[g].reset()
+                oa[g].update_root(og[g])
+    _compare_dist_trees(oracle, agent, oa, range(G), max_nodes)
+    assert agent.store.search_stats(1, 0)["runs"] == moves             # the native loop ran the moves
+    if max_nodes <= 4000:
+        assert agent.store.counter("N_GC") > 0
+
+
+def _compare_dist_trees(oracle, agent, oa, games, max_nodes, oracles=None):
+    import torch
+    s = agent.store
+    assert (s.errors() == 0).all()
+    gs = s.t["gs"].cpu().numpy()
+    for i, g in enumerate(games):
+        o = oa[i] if oracles is None else oracles[i]
+        stat = s.t["obs_stat"][g].view(torch.float32).cpu().numpy()         # [N, 4] = visit, mean, variance, M2
+        dist = s.t["node_dist"][g].cpu().numpy()
+        assert o.error == 0 and gs[g, 0] == o.root and gs[g, 8] == o.n_sims and gs[g, 7] == o.n_expand, (g, gs[g, :10])
+        assert gs[g, 9] == o.n_gc
+        ns, nd = o.dist_arrays()
+        ref = o.arrays()
+        mark = np.zeros(max_nodes, np.uint8)
+        oracle.lib().orc_get_all_childs(o.root, oracle.ptr(ref["child"]), max_nodes, oracle.ptr(mark))
+        occ = np.nonzero(mark)[0]
+        occ = occ[occ != 0]
+        assert stat[occ][:, [0, 1, 2, 3]].tobytes() == np.ascontiguousarray(ns[occ][:, [0, 1, 3, 4]]).tobytes(), g
+        assert dist[occ, :50].tobytes() == np.ascontiguousarray(nd[occ]).tobytes(), g
+        assert np.all(dist[occ, 50:] == 0)
+
+
+def test_sampled_games_of_the_benchmarked_dist_batch(oracle):
+    """BASELINE configs[4] as bench.py runs it: 4096 games x 1000 sims/move, pool 100 000, Model_Dist(seed 0) on the HIP head
+    through the native loop; games 0, 1337 and 4095 against their own oracles (kind 6 + distnet_oracle.c), three moves."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from tetris_mcts_amd import agents, dist as tdist
+    from tetris_mcts_amd.model_distributional import Model_Dist
+    from tetris_mcts_amd.pyTetris import Tetris
+    G, sims, N, moves = 4096, 1000, 100000, 3
+    env_args = ((20, 10), 1, 0, 0)
+    seeds = np.asarray(tdist.game_seeds(20260925, G, 0))
+    model = Model_Dist(atoms=50, seed=0, backend="hip")
+    P = model.flat_params().cpu().numpy()
+    game = Tetris(*env_args, seed=seeds, n_games=G)
+    agent = agents.DistValueSim(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=N, model=model)
+    agent.update_root(game)
+    sample = [0, 1337, 4095]
+    og = [oracle.Game(seed=int(seeds[g])) for g in sample]
+    oa = [oracle.Agent(6, max_nodes=N, low=5, evaluator="distnet", params=P) for _ in sample]
+    for o, gm in zip(oa, og):
+        o.update_root(gm)
+
+    def omove(i):
+        a = oa[i].play(sims)
+        st = oa[i].stats()
+        og[i].play(a)
+        oa[i].update_root(og[i])
+        assert not og[i].end
+        return a, st
+
+    with ThreadPoolExecutor(max_workers=len(sample)) as pool:
+        for m in range(moves):
+            fut = [pool.submit(omove, i) for i in range(len(sample))]
+            act = np.atleast_1d(agent.play())
+            stats = agent.get_stats().reshape(G, 3, 7)
+            game.play(act)
+            agent.update_root(game)
+            assert not np.atleast_1d(game.end).any()
+            for i, g in enumerate(sample):
+                a, st = fut[i].result()
+                assert a == act[g], ("action", m, g, a, act[g], st, stats[g])
+                assert st.tobytes() == stats[g].tobytes(), ("stats", m, g, st, stats[g])
+    gs = agent.store.t["gs"]
+    assert (gs[:, 8] == moves * sims).all() and int(gs[:, 6].abs().sum().item()) == 0
+    _compare_dist_trees(oracle, agent, oa, sample, N)
+    del agent
+    torch.cuda.empty_cache()
+
+
 def test_dist_agent_with_the_distributional_net():
     """The reference's Net (model_distributional.py:18-57, mirrored on PyTorch-ROCm) as the evaluator: distributions stay
     normalised, statistics are finite, every game runs every simulation."""
@@ -106,7 +268,9 @@ def test_dist_agent_with_the_distributional_net():
     G, sims = 64, 100
     env_args = ((20, 10), 1, 0, 0)
     game = Tetris(*env_args, seed=99, n_games=G)
-    agent = agents.DistValueSim(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=8000, model=Model_Dist(atoms=50, seed=0))
+    agent = agents.DistValueSim(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=8000,
+                                model=Model_Dist(atoms=50, seed=0, backend="torch"))
+    assert agent.search_model() is False             # torch ops: the launch loop runs in TreeAgent.mcts
     agent.update_root(game)
     for m in range(3):
         act = agent.play()

@@ -56,6 +56,24 @@ def test_distributional_net_matches_the_reference(golden_dir):
     assert np.allclose(y.sum(1), 1.0, atol=1e-6)
 
 
+def test_distnet_oracle_is_pinned_on_the_reference_net(oracle, golden_dir):
+    """oracle/distnet_oracle.c (one fp32 fma chain per pre-activation, the contract of csrc/distnet.hip) against the
+    reference's own Net run on CPU (model/model_distributional.py:18-57 -> tests/golden/ref_distnet.npz): 1e-6 relative."""
+    g = np.load(os.path.join(golden_dir, "ref_distnet.npz"))
+    keys = ["seq__conv1__weight", "seq__conv1__bias", "seq__conv2__weight", "seq__conv2__bias", "seq__fc1__weight",
+            "seq__fc1__bias", "seq__fc_v__weight", "seq__fc_v__bias"]
+    P = np.concatenate([g[k].ravel() for k in keys]).astype(np.float32)
+    assert P.size == 279232 + 129 * 50
+    x = g["x"]
+    assert (x[:, 0, :2] == 0).all()                      # the fixture's boards leave the two hidden rows empty, as every state does
+    st = np.ascontiguousarray(x[:, 0, 2:, :].reshape(16, 200).astype(np.int8))
+    out = np.zeros((16, 50), np.float32)
+    oracle.lib().orc_distnet_forward(oracle.ptr(P), oracle.ptr(st), 16, 50, oracle.ptr(out))
+    assert np.all(np.abs(out - g["y"]) <= 1e-6 * g["y"])
+    assert np.allclose(out.sum(1), 1.0, atol=1e-6)
+    assert np.allclose(np.log(out.astype(np.float64)), g["lp"], atol=2e-6)
+
+
 # ---- agents/core_distributional.py (numba, fastmath): float tolerance, not bit patterns ----
 RTOL, ATOL = 2e-6, 1e-7      # pure-Python run of the reference (float32 scalars under NumPy 2) vs numba's typing in double
 

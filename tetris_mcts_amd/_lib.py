@@ -56,6 +56,9 @@ SYMBOLS = {
     "tm_valuenet_forward": [vp, vp, vp, i32, vp, vp, vp, vp],
     "tm_valuenet_forward_plain": [vp, vp, i32, vp, vp, vp, vp],
     "tm_valuenet_forward_requests": [vp, vp, C.POINTER(TmStore), vp, vp],
+    "tm_distnet_prepare": [vp, vp, vp],
+    "tm_distnet_forward": [vp, vp, vp, i32, i32, vp, i32, vp, vp],
+    "tm_distnet_forward_requests": [vp, vp, C.POINTER(TmStore), vp, vp],
     "tm_dist_transform": [i32, i32, vp, f64, f64, vp, f64, vp, vp],
     "tm_dist_mean_variance": [i32, i32, vp, f64, f64, vp, vp],
     "tm_distpy_shift": [i32, i32, vp, vp, f64, f64, vp, vp],

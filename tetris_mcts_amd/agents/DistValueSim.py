@@ -7,7 +7,8 @@ its working parts - the file itself does not import (it names `model.ValueSim`, 
   * selection = select_trace_distributional (core_distributional.py:81-104) with the check_low it means to call
     (under-visited children first, low = 5; libc rand()) and policy_dist (:66-79);
   * leaf evaluation = model_distributional.Net (model/model_distributional.py:18-57: softmax over the atoms; input the
-    reference's 22 x 10 board = the 20 visible rows under two empty ones), v_dummy for a finished game;
+    reference's 22 x 10 board = the 20 visible rows under two empty ones) as hand-written HIP kernels (csrc/distnet.hip)
+    launched by the native loop of csrc/search.hip; v_dummy for a finished game;
   * backup = backup_trace_distributional (:108-124) with r = the leaf's score;
   * compute_stats / the action = DistValueSimOnline.py:76-98.
 The tree loop is tree.hip (TM_KIND_DIST: wave_dist_front / wave_dist_back, one lane per atom in the backup); numerics =
@@ -47,12 +48,17 @@ class DistValueSim(TreeAgent):
         self.store = st.TreeStore(self.n_games, self.max_nodes, **kw)
 
     def search_model(self):
-        return False             # the evaluator is a PyTorch module (or a callable): the launch loop runs in TreeAgent.mcts
+        """the HIP head is driven by the native launch loop (search.hip); a Python callable or the torch back end by
+        TreeAgent.mcts"""
+        return self.model if (self.evaluator is None and self.model.backend == "hip") else False
 
     @torch.no_grad()
     def evaluate_requests(self):
         """The pending leaves' observations -> distributions over the atoms, into the store's eval_dist."""
         s = self.store
+        if self.evaluator is None and self.model.backend == "hip":
+            self.model.inference_requests(s)                              # nodes rendered inside the convolution kernel
+            return
         states = s.render_eval()                                          # int8 [G, 200]; all zero where nothing is asked
         if self.evaluator is not None:
             d = torch.as_tensor(np.asarray(self.evaluator(states.cpu().numpy().reshape(-1, 20, 10)), np.float32), device=s.device)

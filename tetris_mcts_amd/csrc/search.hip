@@ -9,9 +9,10 @@
 // pointer chasing, a few waves per SIMD, no matrix work) runs under the value-net kernels of another (MFMA-bound).
 // Per-game results do not depend on n_sub (every game's sequence of events is its own).
 //
-// A game whose node pool runs dry collects garbage in slices, one per launch, instead of simulating (tree.hip gc_run),
-// so it falls behind its quota; after the `sims` regular launches the driver asks how many launches are still needed
-// (tm_sims_remaining) and issues them - they are nearly empty and cost a fraction of a regular one.
+// A game whose node pool runs dry does not simulate while the collector workgroups of the following launches collect its
+// garbage (tree.hip gc_collector_block), so it falls behind its quota; after the `sims` regular launches the driver
+// finishes the collections still under way with collector-only launches (tm_gc_step), asks how many launches are still
+// owed (tm_sims_remaining) and issues them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -168,6 +169,9 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
     };
     auto nn = [&](int k) -> int {
         if (!vn_params || h->sub[k].n_games == 0) return 0;
+        if (h->full.kind == TM_KIND_DIST)      // the distributional head (distnet.hip): eval_obs names the leaf node
+            return tm_distnet_forward_requests(vn_params, vn_prepared, &h->sub[k],
+                                               vn_scratch + (size_t)h->first[k] * TM_DISTNET_SCRATCH, st[k]);
         float* scr = vn_scratch + (size_t)h->first[k] * h->full.eval_slots * TM_VALUENET_SCRATCH_MFMA;
         return tm_valuenet_forward_requests(vn_params, vn_prepared, &h->sub[k], scr, st[k]);
     };

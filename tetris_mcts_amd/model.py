@@ -56,7 +56,8 @@ class Model_VV:
         self.backend = backend
         self._flat = None
         self._prepared = None
-        self._scratch = None
+        self._scratch = None         # "hip": zero-filled rows of SCRATCH_MFMA floats (k_vn_fc1 keeps a counter per 32 states in them)
+        self._scratch_plain = None   # "hip_plain": its own buffer - never handed to the matrix-core kernels
 
     def training(self, mode=True):
         self.model.train(mode)
@@ -153,10 +154,10 @@ class Model_VV:
             _lib.check(_lib.lib().tm_valuenet_forward(_p(P), _p(self._prepared), _p(states), B, _p(v_out), _p(var_out),
                                                       _p(self._scratch), _stream()), "tm_valuenet_forward")
         elif self.backend == "hip_plain":
-            if self._scratch is None or self._scratch.shape[0] < B:
-                self._scratch = torch.empty(B, 9728, dtype=torch.float32, device=self.device)
+            if self._scratch_plain is None or self._scratch_plain.shape[0] < B:
+                self._scratch_plain = torch.empty(B, 9728, dtype=torch.float32, device=self.device)
             _lib.check(_lib.lib().tm_valuenet_forward_plain(_p(self.flat_params()), _p(states), B, _p(v_out), _p(var_out),
-                                                            _p(self._scratch), _stream()), "tm_valuenet_forward_plain")
+                                                            _p(self._scratch_plain), _stream()), "tm_valuenet_forward_plain")
         else:
             out = self.model(states.reshape(B, 1, 20, 10).float())
             v_out.copy_(out[:, 0])
