@@ -454,7 +454,8 @@ def _cpu_worker(kind, sims, max_nodes, lp, seconds, seed, state_dict, q, warm=5,
                         ag.update_root(g)
                 play_window(step, lambda cnt=cnt: (cnt[0], cnt[1]))
             else:
-                params = torch.cat([state_dict[kk].reshape(-1).float() for kk in state_dict]).numpy()
+                from tetris_mcts_amd.model import PARAM_ORDER      # (a state_dict lists out_ubound / out_lbound first)
+                params = torch.cat([state_dict[kk].reshape(-1).float() for kk in PARAM_ORDER]).numpy()
                 g = B.Game(seed=gseed)
                 a = B.Agent(1 if lp else 0, max_nodes=max_nodes, evaluator="valuenet", params=params)
                 a.update_root(g)

@@ -52,7 +52,7 @@ enum {
     TM_GS_ERR, TM_GS_N_EXPAND, TM_GS_N_SIMS, TM_GS_N_GC, TM_GS_RNG_POS, TM_GS_N_NQ_FALLBACK,
     TM_GS_LEAF, TM_GS_LEAF_END, TM_GS_K_EVAL, TM_GS_LEAF_SCORE,
     TM_GS_TRACE_SUM, /* sum of trace lengths over all simulations (for bytes/simulation accounting) */
-    TM_GS_N_EVAL,    /* leaf states handed to the evaluator */
+    TM_GS_N_EVAL,    /* leaf states handed to the evaluator (requests posted) */
     TM_GS_N_POOL_RESET, /* tm_pool_reset calls that hit this game */
     TM_GS_MAX_TRACE,    /* longest trace of any simulation so far */
     TM_GS_CYC_BACK = 20, TM_GS_CYC_SELECT, TM_GS_CYC_EXPAND, /* shader cycles of the last simulation's phases */
@@ -81,8 +81,12 @@ enum {
     TM_GS_GC_IN_MOVE,    /* a collection has completed since the root last moved: until it moves again nothing becomes unreachable
                             (the search only adds links), so the next exhaustion is counted as the reference's collection that
                             frees nothing (agents/agent.py:96-97) and goes straight to TM_GS_POOL_FULL */
-    TM_GS_GC_REQ_AT      /* the launch in which the game asked for the collection it is waiting for (the waiting games' steps that
+    TM_GS_GC_REQ_AT,     /* the launch in which the game asked for the collection it is waiting for (the waiting games' steps that
                             do not all fit a launch are served oldest request first) */
+    TM_GS_LEAF_OBS,      /* the pending leaf's observation (TM_SIM_EVAL_NEEDED: where the backup files the evaluator's output) */
+    TM_GS_N_EVAL_SKIP,   /* leaf-parallel kinds: unique children of expanded leaves whose evaluation the backup would discard
+                            (observation already visited / finished) - not posted under TM_SIM_EVAL_NEEDED, counted always */
+    TM_GS_N_EVAL_CACHED  /* TM_KIND_VALUESIM / TM_KIND_CPPAGENT under TM_SIM_EVAL_NEEDED: leaves answered from obs_eval */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
@@ -157,7 +161,21 @@ typedef struct tm_store {
     int32_t dist_bins;
     int32_t gc_spec_nodes; /* a game with fewer free nodes than this has its tree marked speculatively while it goes on simulating
                               (tree.hip GC_SPEC_*); 0: never */
+    /* dense evaluation requests: beside the per-game slots (eval_obs) every tm_sim_step launch appends the requests it posts to
+       a list the built-in evaluators draw dense work from (conv waves, 32-row FC tiles).  TM_EVAL_SEGS(n_games) segments (game
+       g appends to segment g % segs: one device atomic per game and launch, spread over the segments' counters); entry d of
+       segment s lives at eval_list[(s + segs * (d / eval_slots)) * eval_slots + d % eval_slots].  Two sets of counters: a launch
+       with TM_SIM_FRONT appends under eval_parity and clears the other set, so the CALLER FLIPS eval_parity before every such
+       launch and hands the same value to the evaluator call that follows; tm_move_begin clears both. */
+    int32_t *eval_list;   /* [G*eval_slots][2] (request slot, observation index) */
+    int32_t *eval_cnt;    /* [G][2] entries per segment and parity (segment s of the games of *this at [s][parity]) */
+    /* TM_KIND_VALUESIM / TM_KIND_CPPAGENT with TM_SIM_EVAL_NEEDED: the evaluator's output per observation, (v, var, epoch bits, 0);
+       valid while epoch == eval_epoch (>= 1; the owner of the weights bumps it when they change); NULL: no cache */
+    float *obs_eval;      /* [G][N][4] */
+    int32_t eval_parity;  /* 0 / 1, see eval_list */
+    int32_t eval_epoch;
 } tm_store;
+#define TM_EVAL_SEGS(n_games) ((n_games) < 64 ? (n_games) : 64)
 
 /* pools, free lists, tables, rng (seed 1), control blocks.  Everything else must be zero-filled by the caller. */
 int tm_pool_init(const tm_store *s, void *stream);
@@ -199,6 +217,12 @@ int tm_gc_step(const tm_store *s, void *stream);
 #define TM_SIM_BACKUP 1  /* finish the pending simulation: backup with eval_v/eval_var */
 #define TM_SIM_FRONT 2   /* start one: select, expand, post evaluation requests into eval_obs */
 #define TM_SIM_GC_FULL 4 /* a game that is collecting garbage finishes the collection in this launch (catch-up launches) */
+#define TM_SIM_EVAL_NEEDED 8 /* the evaluator is a pure function of the observation (the built-in value net): post only the
+                                requests whose outputs the backup will use - leaf-parallel kinds: the children on their first
+                                visit (core.h:341-350; agent.cpp:536-545: and not finished); TM_KIND_VALUESIM / TM_KIND_CPPAGENT:
+                                not a leaf whose observation was evaluated under the current weights (s->obs_eval).  Results
+                                are identical either way; a Python evaluator callable keeps receiving all k children
+                                (agent.cpp:424-436), so the Python-driven loop does not set it */
 int tm_sim_step(const tm_store *s, int flags, void *stream);
 int tm_eval_render(const tm_store *s, int8_t *out /* [G*eval_slots][200] */, void *stream);
 
@@ -222,6 +246,9 @@ void tm_search_destroy(tm_search *h);
 int tm_search_run(tm_search *h, int sims, const float *vn_params, const float *vn_prepared, float *vn_scratch,
                   void *stream);
 int tm_search_stats(tm_search *h, double *out, int n, int reset);
+/* the evaluator's weights changed: s->eval_epoch of the handle's copy of the store (outputs filed in obs_eval under another
+ * epoch are not used; epochs are >= 1 and never reused for other weights) */
+int tm_search_set_epoch(tm_search *h, int epoch);
 int tm_root_stats(const tm_store *s, float *stats /* [G][3][7] */, int32_t *action /* [G] */, void *stream);
 /* one game's tree in the reference's array layout (agents/agent.py:58-88), for inspection and tests */
 int tm_export_game(const tm_store *s, int game, int32_t *child /* [N][7] */, float *score, int32_t *n_to_o,

@@ -55,7 +55,7 @@ def lib():
         for name in ("root", "episode", "error", "n_avail", "n_obs_avail", "memory_index"):
             f = getattr(L, "orc_agent_" + name)
             f.restype, f.argtypes = i32, [vp]
-        for name in ("n_sims", "n_expand", "n_gc", "n_eval_states", "trace_len_sum", "max_trace_len"):
+        for name in ("n_sims", "n_expand", "n_gc", "n_eval_states", "trace_len_sum", "max_trace_len", "n_eval_used", "n_eval_repeat"):
             f = getattr(L, "orc_agent_" + name)
             f.restype, f.argtypes = C.c_long, [vp]
         L.orc_agent_set_mt.argtypes = [vp, vp]
@@ -264,7 +264,7 @@ class Agent:
 
     def __getattr__(self, name):
         if name in ("root", "episode", "error", "n_avail", "n_obs_avail", "memory_index", "n_sims", "n_expand",
-                    "n_gc", "n_eval_states", "trace_len_sum", "max_trace_len", "n_rollout_steps"):
+                    "n_gc", "n_eval_states", "trace_len_sum", "max_trace_len", "n_rollout_steps", "n_eval_used", "n_eval_repeat"):
             return getattr(self.L, "orc_agent_" + name)(self.h)
         raise AttributeError(name)
 

@@ -130,7 +130,16 @@ def test_sampled_games_of_a_real_4096_game_batch(oracle, name, moves, n_sub):
     assert int(gs[:, 6].abs().sum().item()) == 0
     if name == "ValueSimLP":
         assert agent.store.eval_slots == 7 and agent.store.t["eval_obs"].numel() == 28672
-        assert int(gs[:, 17].sum().item()) > 3 * int(gs[:, 7].sum().item())     # several evaluated states per expansion
+        # several unique children per expansion; only those on their first visit are posted to the net (TM_SIM_EVAL_NEEDED)
+        posted, skipped, expanded = int(gs[:, 17].sum().item()), int(gs[:, 48].sum().item()), int(gs[:, 7].sum().item())
+        assert posted + skipped > 3 * expanded and skipped > 0 and posted > expanded
+        used = sum(o.a.n_eval_used for o in orc)
+        assert sum(int(gs[g, 17].item()) for g in [0, 1337, 4095]) == used          # exactly the ones the backup uses
+        assert sum(int(gs[g, 17].item() + gs[g, 48].item()) for g in [0, 1337, 4095]) == sum(o.a.n_eval_states for o in orc)
+    else:
+        # ValueSim: a leaf whose observation was evaluated before (under the same weights) is answered from obs_eval
+        assert sum(int(gs[g, 49].item()) for g in [0, 1337, 4095]) == sum(o.a.n_eval_repeat for o in orc)
+        assert sum(int(gs[g, 17].item() + gs[g, 49].item()) for g in [0, 1337, 4095]) == sum(o.a.n_eval_states for o in orc)
     del agent
     torch.cuda.empty_cache()
 

@@ -24,6 +24,7 @@ class TmStore(C.Structure):
         ("gc_mark", vp), ("gc_queue", vp), ("replay_obs", vp), ("replay_stat", vp), ("replay_count", vp), ("mt_state", vp), ("node_child", vp), ("gc_part", vp),
         ("node_dist", vp), ("eval_dist", vp), ("nq_table_d", vp), ("dist_vmin", f64), ("dist_vmax", f64), ("dist_bins", i32),
         ("gc_spec_nodes", i32),
+        ("eval_list", vp), ("eval_cnt", vp), ("obs_eval", vp), ("eval_parity", i32), ("eval_epoch", i32),
     ]
 
 
@@ -68,6 +69,7 @@ SYMBOLS = {
     "tm_search_create": [C.POINTER(vp), C.POINTER(TmStore), i32, i32],
     "tm_search_run": [vp, i32, vp, vp, vp, vp],
     "tm_search_stats": [vp, vp, i32, i32],
+    "tm_search_set_epoch": [vp, i32],
 }
 
 _lib = None

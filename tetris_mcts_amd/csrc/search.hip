@@ -79,6 +79,9 @@ int tm_store_slice(const tm_store* s, int first, int n, tm_store* out) {
     if (t.replay_stat) t.replay_stat += f * (size_t)s->replay_cap * 4;
     if (t.replay_count) t.replay_count += f;
     if (t.mt_state && (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)) t.mt_state += f * 625;
+    t.eval_list += f * (size_t)s->eval_slots * 2;
+    t.eval_cnt += f * 2;
+    if (t.obs_eval) t.obs_eval += f * N * 4;
     *out = t;
     return 0;
 }
@@ -165,7 +168,9 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
     auto step = [&](int k, int extra = 0) -> int {
         if (h->sub[k].n_games == 0) return 0;
         h->launches += 1;
-        return tm_sim_step(&h->sub[k], TM_SIM_BACKUP | TM_SIM_FRONT | extra, st[k]);
+        h->sub[k].eval_parity ^= 1;      // the dense request list: every launch appends under the other parity (tm_store::eval_list)
+        // the evaluator is the built-in net, a function of the observation: only the requests whose outputs the backup uses
+        return tm_sim_step(&h->sub[k], TM_SIM_BACKUP | TM_SIM_FRONT | (vn_params ? TM_SIM_EVAL_NEEDED : 0) | extra, st[k]);
     };
     auto nn = [&](int k) -> int {
         if (!vn_params || h->sub[k].n_games == 0) return 0;
@@ -240,6 +245,14 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
         if (hipEventElapsedTime(&ms, h->ev_loop0, h->ev_loop1) == hipSuccess) { h->loop_ms += ms; h->loop_sims += sims; }
     }
     h->n_runs += 1;
+    return 0;
+}
+
+// The weights of the built-in evaluator changed (or are another model's): outputs filed under another epoch are not used
+// (tm_store::obs_eval, TM_SIM_EVAL_NEEDED).  The handle holds its own copy of the store description.
+int tm_search_set_epoch(tm_search* h, int epoch) {
+    h->full.eval_epoch = epoch;
+    for (auto& t : h->sub) t.eval_epoch = epoch;
     return 0;
 }
 

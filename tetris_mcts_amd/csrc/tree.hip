@@ -400,6 +400,8 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         // visit, value, variance = 0 and obs_arrays['end'] (agents/agent.py:123): slots are initialised when they are
         // handed out, so the GC does not have to clear the key / record streams of everything it frees
         *reinterpret_cast<uint4*>(P.stat() + (size_t)o * 4) = make_uint4((ok[11] & 1u) << 31, 0u, 0u, 0u);
+        // ... and nothing is known about it yet (the evaluator's output per observation, TM_SIM_EVAL_NEEDED)
+        if (S.obs_eval) *reinterpret_cast<uint4*>(S.obs_eval + ((size_t)g * P.n() + (size_t)o) * 4) = make_uint4(0u, 0u, 0u, 0u);
     }
     {   // same observation as an earlier new candidate
         int osrc = shfl_u32((uint32_t)o, odup);
@@ -715,10 +717,20 @@ __device__ inline bool trace_has_repeat(const GP& P, int lane, int len, const in
     return __any(rep);
 }
 
+// The evaluator's output for the leaf's observation, filed for later leaves with the same observation (TM_SIM_EVAL_NEEDED: the
+// built-in value net is a function of the rendered observation and of the weights, whose version is S.eval_epoch).  Only a
+// request that was really posted is filed (K_EVAL == 1; a leaf answered from the cache has K_EVAL == 0).
+__device__ __forceinline__ void eval_cache_store(const tm_store& S, const GP& P, int lane, int gsv, int eflags, int leaf_end) {
+    if (!(eflags & TM_SIM_EVAL_NEEDED) || !S.obs_eval || leaf_end || GSV(gsv, TM_GS_K_EVAL) != 1) return;
+    if (lane == 0)
+        *reinterpret_cast<uint4*>(S.obs_eval + ((size_t)P.g * P.n() + (size_t)GSV(gsv, TM_GS_LEAF_OBS)) * 4) =
+            make_uint4(__float_as_uint(P.eval_v()[0]), __float_as_uint(P.eval_var()[0]), (uint32_t)S.eval_epoch, 0u);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the back half of a simulation: ValueSim.py:83-94 / ValueSimLP.py:59-70 / agent.cpp:432-446,458
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L, int lane, int gsv) {
+__device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, WaveLds& L, int lane, int gsv, int eflags) {
     const int len = GSV(gsv, TM_GS_TRACE_LEN);
     const int leaf_end = GSV(gsv, TM_GS_LEAF_END);
     const int k = GSV(gsv, TM_GS_K_EVAL);
@@ -736,10 +748,12 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
     } else if (kind == TM_KIND_VALUESIM) {
         v0 = (double)leaf_score;   // Python int score + np.float32 v under numpy 1.17 = float64
         if (!leaf_end) { v0 = v0 + (double)P.eval_v()[0]; var0 = (double)P.eval_var()[0]; }
+        eval_cache_store(S, P, lane, gsv, eflags, leaf_end);
     } else if (kind == TM_KIND_CPPAGENT) {
         float ls = (float)leaf_score;   // score[trace.back()] is a float array element
         if (!leaf_end) { v0 = (double)(ls + P.eval_v()[0]); var0 = (double)P.eval_var()[0]; }
         else v0 = (double)ls;
+        eval_cache_store(S, P, lane, gsv, eflags, leaf_end);
     } else {
         // leaf-parallel: first-visit initialisation of the unique children, then the averaged target
         if (S.app > 1) seq = trace_has_repeat(P, lane, len, P.leaf() + 7, k);
@@ -790,10 +804,14 @@ __device__ __forceinline__ void wave_sim_back(const tm_store& S, const GP& P, Wa
 // ---------------------------------------------------------------------------------------------------
 template <bool VANILLA>
 __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int leaf,
-                                                  int leaf_end, uint32_t self_o, uint32_t self_sc, int gsv, int gc_req_word) {
+                                                  int leaf_end, uint32_t self_o, uint32_t self_sc, int gsv, int gc_req_word,
+                                                  int eflags) {
     const long long tc0 = __builtin_readcyclecounter();
     const int kind = S.kind;
-    int k_eval = 0;
+    int k_eval = 0;                 // what the backup finds in TM_GS_K_EVAL: the leaf's unique children (leaf-parallel kinds), else requests posted
+    int n_post = 0, n_skip = 0, n_cached = 0;
+    bool post = false;              // this lane's request slot carries a request
+    uint32_t post_obs = 0;
     if (!leaf_end) {
         uint32_t lh;
         if (!wave_expand(S, P, L, g, lane, leaf, self_sc, lh, gsv, gc_req_word)) {
@@ -805,18 +823,52 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
             k_eval = 0;
             if (lane < S.eval_slots) P.eval_obs()[lane] = 0;
         } else if (kind == TM_KIND_VALUESIM || kind == TM_KIND_CPPAGENT || kind == TM_KIND_DIST) {
-            k_eval = 1;      // (TM_KIND_DIST: the request names the leaf NODE - identity projection)
-            if (lane == 0) P.eval_obs()[0] = (int)self_o;
+            // (TM_KIND_DIST: the request names the leaf NODE - identity projection)
+            bool hit = false;
+            if ((eflags & TM_SIM_EVAL_NEEDED) && S.obs_eval && kind != TM_KIND_DIST) {
+                // this observation has been a leaf before (another node, same board and piece) under the same weights:
+                // the evaluator would return the same two floats
+                const uint4 ce = *reinterpret_cast<const uint4*>(S.obs_eval + ((size_t)g * P.n() + (size_t)self_o) * 4);
+                hit = S.eval_epoch > 0 && (int)ce.z == S.eval_epoch;
+                if (hit && lane == 0) { P.eval_v()[0] = __uint_as_float(ce.x); P.eval_var()[0] = __uint_as_float(ce.y); }
+            }
+            n_cached = hit ? 1 : 0;
+            k_eval = n_post = hit ? 0 : 1;
+            post = lane == 0 && !hit;
+            post_obs = self_o;
+            if (lane == 0) P.eval_obs()[0] = hit ? 0 : (int)self_o;
         } else {
-            // unique children of the freshly expanded leaf (ValueSimLP.py:55 / agent.cpp:424)
+            // unique children of the freshly expanded leaf (ValueSimLP.py:55 / agent.cpp:424).  The backup uses a child's
+            // output only to initialise an observation on its first visit (core.h:341-350; agent.cpp:536-545: unless it is a
+            // finished one): those are counted, and under TM_SIM_EVAL_NEEDED only those are posted.
             const int nu = (int)(lh & 7u);
             k_eval = nu;
+            uint32_t sx = 0;
+            if (lane < nu) sx = P.stat()[(size_t)L.misc[24 + lane] * 4];
+            const bool used = lane < nu && (sx & 0x7FFFFFFFu) == 0u && !(kind == TM_KIND_CPPAGENT_LP && (sx >> 31) != 0u);
+            post = lane < nu && (used || !(eflags & TM_SIM_EVAL_NEEDED));
+            n_skip = nu - __popcll(__ballot(used));
+            n_post = __popcll(__ballot(post));
+            post_obs = lane < nu ? L.misc[24 + lane] : 0u;
             if (lane < 7) {
                 bool on = lane < nu;
                 P.leaf()[lane] = on ? (int)L.misc[16 + lane] : 0;
                 P.leaf()[7 + lane] = on ? (int)L.misc[24 + lane] : 0;
                 P.leaf()[14 + lane] = on ? (int)L.misc[32 + lane] : 0;
-                P.eval_obs()[lane] = on ? (int)L.misc[24 + lane] : 0;
+                P.eval_obs()[lane] = post ? (int)L.misc[24 + lane] : 0;
+            }
+        }
+        if (n_post > 0) {
+            // the dense request list (include/tetris_mcts_hip.h, eval_list): one atomic per game and launch
+            const int slots = S.eval_slots, segs = TM_EVAL_SEGS(S.n_games), seg = g % segs;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&S.eval_cnt[(size_t)seg * 2 + S.eval_parity], n_post);
+            base = (int)rl_u32((uint32_t)base, 0);
+            const uint64_t pm = __ballot(post);
+            if (post) {
+                const int d = base + __popcll(pm & ((1ull << lane) - 1ull));
+                const int at = (seg + segs * (d / slots)) * slots + d % slots;
+                reinterpret_cast<int2*>(S.eval_list)[at] = make_int2(g * slots + lane, (int)post_obs);
             }
         }
         if (lane == 0) P.gs()[TM_GS_N_EXPAND] = GSV(gsv, TM_GS_N_EXPAND) + 1;
@@ -829,7 +881,10 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
         gs[TM_GS_PENDING] = 1;
         gs[TM_GS_GC_RETRY] = 0;
         gs[TM_GS_K_EVAL] = k_eval;
-        gs[TM_GS_N_EVAL] = GSV(gsv, TM_GS_N_EVAL) + k_eval;
+        gs[TM_GS_N_EVAL] = GSV(gsv, TM_GS_N_EVAL) + n_post;
+        gs[TM_GS_LEAF_OBS] = (int)self_o;
+        if (n_skip) gs[TM_GS_N_EVAL_SKIP] = GSV(gsv, TM_GS_N_EVAL_SKIP) + n_skip;
+        if (n_cached) gs[TM_GS_N_EVAL_CACHED] = GSV(gsv, TM_GS_N_EVAL_CACHED) + n_cached;
         // nearly out of nodes: have the tree marked while the game goes on (GC_SPEC_*), unless a collection could not help
         // ... and only if the pool can run dry in THIS move (seven nodes a simulation at most): update_root drops the marks
         if (S.gc_spec_nodes > 0 && GSV(gsv, TM_GS_GC_PHASE) == 0 && !leaf_end && !GSV(gsv, TM_GS_POOL_FULL) && !gs[TM_GS_POOL_FULL]) {
@@ -844,7 +899,7 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
 // ---------------------------------------------------------------------------------------------------
 template <bool VANILLA>
 __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, WaveLds& L, MtLds* M, int g, int lane, int gsv,
-                                               int gc_req_word) {
+                                               int gc_req_word, int eflags) {
     const long long tc_start = __builtin_readcyclecounter();
     if (lane < 32) L.misc[lane] = S.rng[(size_t)g * 32 + lane];      // glibc rand() state (31 words), used by check_low only
     wave_sync();
@@ -1143,7 +1198,7 @@ __device__ __forceinline__ void wave_sim_front(const tm_store& S, const GP& P, W
         if (lane < 32) S.rng[(size_t)g * 32 + lane] = rng_keep;
         if (lane == 0) P.gs()[TM_GS_RNG_POS] = rng_pos;
     }
-    wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end | (overflow ? 1 : 0), self_o, self_sc, gsv, gc_req_word);
+    wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end | (overflow ? 1 : 0), self_o, self_sc, gsv, gc_req_word, eflags);
 }
 
 __device__ __forceinline__ bool bit_test_set(uint8_t* bm, uint32_t i) {
@@ -1235,7 +1290,7 @@ __device__ __forceinline__ void wave_dist_back(const tm_store& S, const GP& P, W
 // argmax (np.argmax: the first NaN wins).  One 8-lane group per unique child (the record's pieces), one dependent pair of
 // loads per level (record -> children's statistics).
 template <bool VANILLA>
-__device__ __forceinline__ void wave_dist_front(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int gsv, int gc_req_word) {
+__device__ __forceinline__ void wave_dist_front(const tm_store& S, const GP& P, WaveLds& L, int g, int lane, int gsv, int gc_req_word, int eflags) {
     const long long tc_start = __builtin_readcyclecounter();
     if (lane < 32) L.misc[lane] = S.rng[(size_t)g * 32 + lane];
     wave_sync();
@@ -1330,7 +1385,7 @@ __device__ __forceinline__ void wave_dist_front(const tm_store& S, const GP& P, 
         if (lane < 32) S.rng[(size_t)g * 32 + lane] = rng_keep;
         if (lane == 0) P.gs()[TM_GS_RNG_POS] = rng_pos;
     }
-    wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end, cur.y, cur.z, gsv, gc_req_word);
+    wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, leaf_end, cur.y, cur.z, gsv, gc_req_word, eflags);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2225,6 +2280,10 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     const int n_gc = gc_blocks(S.n_games);
     if ((int)blockIdx.x < n_gc) {
         static_assert(sizeof(WaveLds) * WPB >= sizeof(GcLds), "collector scratch");
+        // the dense request list: this launch appends under S.eval_parity; the other set of counters (the list the evaluator
+        // drew from before this launch) is cleared for the next one
+        if (blockIdx.x == 0 && (flags & TM_SIM_FRONT) && (int)threadIdx.x < TM_EVAL_SEGS(S.n_games))
+            S.eval_cnt[(size_t)threadIdx.x * 2 + (S.eval_parity ^ 1)] = 0;
         gc_collector_block(S, flags, n_gc, *reinterpret_cast<GcLds*>(lds));
         return;
     }
@@ -2256,22 +2315,22 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         const int leaf = GSV(gsv, TM_GS_LEAF);
         const uint32_t self_o = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_OBS];
         const uint32_t self_sc = P.rec()[(size_t)leaf * TM_REC_DW + TM_REC_SCORE];
-        wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc, gsv, gc_req_word);
+        wave_front_finish<VANILLA>(S, P, L, g, lane, leaf, 0, self_o, self_sc, gsv, gc_req_word, flags);
         return;
     }
     const bool dist = !VANILLA && S.kind == TM_KIND_DIST;
     const long long t0 = __builtin_readcyclecounter();
     if ((flags & TM_SIM_BACKUP) && pend == 1) {
         if (dist) wave_dist_back(S, P, L, g, lane, gsv);
-        else wave_sim_back(S, P, L, lane, gsv);
+        else wave_sim_back(S, P, L, lane, gsv, flags);
         __threadfence_block();
     }
     const long long t1 = __builtin_readcyclecounter();
     if (lane == 0) gs[TM_GS_CYC_BACK] = (int)(t1 - t0);
     // the per-move quota (tm_move_begin): games that lost launches to a collection catch up in extra launches
     if ((flags & TM_SIM_FRONT) && GSV(gsv, TM_GS_SIM_STARTED) < GSV(gsv, TM_GS_SIM_TARGET)) {
-        if (dist) wave_dist_front<VANILLA>(S, P, L, g, lane, gsv, gc_req_word);
-        else wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane, gsv, gc_req_word);
+        if (dist) wave_dist_front<VANILLA>(S, P, L, g, lane, gsv, gc_req_word, flags);
+        else wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane, gsv, gc_req_word, flags);
     }
     else if (lane < S.eval_slots) P.eval_obs()[lane] = 0;   // nothing started: no request (the evaluator skips empty slots)
 }
@@ -2282,6 +2341,10 @@ __global__ void k_move_begin(tm_store S, int sims) {
     if (g >= S.n_games) return;
     int32_t* gs = S.gs + (size_t)g * TM_GS_DW;
     gs[TM_GS_SIM_TARGET] = gs[TM_GS_SIM_STARTED] + sims;
+    // no request is pending between two moves: both sets of the dense list's counters start the move empty, whatever parity
+    // the caller's launches go on with
+    S.eval_cnt[(size_t)g * 2] = 0;
+    S.eval_cnt[(size_t)g * 2 + 1] = 0;
 }
 // launches still needed before every game has finished its quota: max over games of (simulations not started yet
 // + one launch for the pending backup + one if a collection is in progress); atomicMax into *out (zeroed by the caller)

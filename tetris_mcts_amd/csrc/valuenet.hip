@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
 #include "../../include/tetris_mcts_hip.h"
 
 namespace tmcts_vn {
@@ -200,9 +201,9 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, const in
     }
 }
 
-// Input: either int8 states [n][200], or (states == nullptr) evaluation requests of the tree engine:
-// request s refers to packed observation eval_obs[s] of game s / eval_slots (ENGINE_SPEC.md section 7), rendered
-// here on the fly (0 empty, 1 locked, -1 falling piece; request 0 = unused slot = empty board).
+// Input: either int8 states [n][200], or (states == nullptr) the evaluation requests of the tree engine's dense list (ReqList
+// below): entry p = (request slot, packed observation of the slot's game, ENGINE_SPEC.md section 7), rendered here on the fly
+// (0 empty, 1 locked, -1 falling piece).
 #if TM_CONV_WG_PER_CU == 2 && !defined(TM_CONV_CAP256)
 #define TM_CONV_CAP256   // two waves per SIMD: 256 registers each
 #endif
@@ -211,6 +212,32 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, const in
 #else
 #define TM_CONV_WAVES 1
 #endif
+// The tree engine's dense request list (include/tetris_mcts_hip.h, tm_store::eval_list): `segs` segments with one counter
+// each under the current parity; entry d of segment sg is list[(sg + segs * (d / slots)) * slots + d % slots] = (request slot,
+// observation index).  Dense position p counts through the segments in order.
+struct ReqList {
+    const int2* list;
+    const int32_t* cnt;
+    int parity, segs, slots;
+};
+// lane i: inclusive prefix of the segments' counts; total = the number of requests
+__device__ __forceinline__ int req_prefix(const ReqList& rq, int lane, int& total) {
+    int incl = lane < rq.segs ? rq.cnt[lane * 2 + rq.parity] : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    total = __shfl(incl, 63, 64);
+    return incl;
+}
+// index into rq.list of dense position p (wave-uniform, p < total; every lane of the wave calls it)
+__device__ __forceinline__ int req_at(const ReqList& rq, int incl, int p, int lane) {
+    const int sg = __popcll(__ballot(lane < rq.segs && incl <= p));     // the first segment whose inclusive prefix exceeds p
+    const int before = __shfl(incl, sg > 0 ? sg - 1 : 0, 64);
+    const int d = p - (sg > 0 ? before : 0);
+    return (sg + rq.segs * (d / rq.slots)) * rq.slots + d % rq.slots;
+}
 #include "valuenet_conv.inc"
 
 // fc1 (1792 -> 256) + ReLU on v_mfma_f32_16x16x4_f32 (D[16x16] += A[16x4] B[4x16]; lane l: A[i=l&15][k=l>>4],
@@ -233,15 +260,24 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
                                                 float* __restrict__ hout, int hstride,
-                                                const int32_t* __restrict__ eval_obs, int32_t* __restrict__ cnt, int cnt_stride,
+                                                ReqList rq, int32_t* __restrict__ cnt, int cnt_stride,
                                                 float* __restrict__ v_out, float* __restrict__ var_out) {
     __shared__ float bt[2][32 * FC_PITCH];
+    __shared__ int row_slot[32];          // request mode: where row j of the tile delivers its outputs
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, l15 = lane & 15;
     const int s0 = blockIdx.x * 32;
-    if (eval_obs) {
-        // a tile of 32 request slots none of which carries a request (catch-up launches, finished games): nothing to do
-        const bool mine = threadIdx.x < 32 && s0 + (int)threadIdx.x < n && eval_obs[s0 + threadIdx.x] != 0;
-        if (!__syncthreads_or(mine)) return;
+    if (rq.list) {
+        // rows = dense positions of the request list; a tile past its end has nothing to do (both of its workgroups leave)
+        const int incl = req_prefix(rq, lane, n);
+        if (s0 >= n) return;
+        if (w == 0) {
+            for (int j = 0; j < 32; ++j) {
+                const int p = s0 + j < n ? s0 + j : n - 1;
+                const int at = req_at(rq, incl, p, lane);
+                if (lane == 0) row_slot[j] = rq.list[at].x;
+            }
+        }
+        // (read after the __syncthreads of the K loop)
     }
     const int ht = blockIdx.y * 8 + w;   // 16-row hidden tile 0..15
     const float4* W = reinterpret_cast<const float4*>(prep + PREP_W1) + (size_t)ht * 112 * 64 + lane;
@@ -344,8 +380,11 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     if (threadIdx.x < 64) {
         // one chain per lane: state j = lane >> 1, output o = lane & 1 (k_fc_out's thread t = 2 s + o); fma over the 256
         // hidden units in order
-        const int j = threadIdx.x >> 1, o = threadIdx.x & 1, sidx = s0 + j;
-        if (sidx < n && !(eval_obs && eval_obs[sidx] == 0)) {
+        const int j = threadIdx.x >> 1, o = threadIdx.x & 1;
+        int sidx = s0 + j;
+        const bool live = sidx < n;
+        if (rq.list) sidx = row_slot[j];
+        if (live) {
             float acc = P[OFF_FOB + o];
             const float* x = &hs[j * HS_PITCH];
             const float* wr = P + OFF_FOW + o * HID;
@@ -393,37 +432,39 @@ int tm_valuenet_forward_plain(const float* P, const int8_t* states, int n, float
 }
 
 static int vn_forward_impl(const float* P, const float* prepared, const int8_t* states, const uint32_t* obs_key,
-                           const int32_t* eval_obs, int eval_slots, int max_nodes, int n, float* v, float* var,
+                           const ReqList& rq, int max_nodes, int n, float* v, float* var,
                            float* scratch, hipStream_t stream) {
     if (n <= 0) return 0;
     constexpr int SS = TM_VALUENET_SCRATCH_MFMA;   // a3 (1792) + hidden (256) + 16 pad words (word 0 of a tile's first row: its arrival counter)
     static_assert(SS >= A3 + HID + 1 && SS % 4 == 0, "scratch row");
-    static bool attr_set = false;
     const int lds = 4 * WAVE_LDS * (int)sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_vn_conv),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    static int attr_err = 0;
+    std::call_once(attr_once, [&] {
+        attr_err = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vn_conv),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    if (attr_err) return attr_err;
     int blocks = (n + 3) / 4;
     if (blocks > 256 * TM_CONV_WG_PER_CU) blocks = 256 * TM_CONV_WG_PER_CU;   // resident workgroups, waves stride over the states
-    hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, eval_obs,
-                       eval_slots, max_nodes, n, scratch, SS);
+    hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, rq,
+                       max_nodes, n, scratch, SS);
     hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(512), 0, stream, P, prepared, scratch, SS, n,
-                       scratch + A3, SS, eval_obs, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
+                       scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
     return (int)hipGetLastError();
 }
 
 // matrix-core path; prepared: tm_valuenet_prepare output; scratch: n x TM_VALUENET_SCRATCH_MFMA floats
 int tm_valuenet_forward(const float* P, const float* prepared, const int8_t* states, int n, float* v, float* var,
                         float* scratch, void* stream_) {
-    return vn_forward_impl(P, prepared, states, nullptr, nullptr, 1, 0, n, v, var, scratch, (hipStream_t)stream_);
+    return vn_forward_impl(P, prepared, states, nullptr, ReqList{nullptr, nullptr, 0, 0, 1}, 0, n, v, var, scratch, (hipStream_t)stream_);
 }
 
 // the tree engine's evaluation requests, rendered inside the first kernel: v/var -> s->eval_v / s->eval_var
 int tm_valuenet_forward_requests(const float* P, const float* prepared, const tm_store* s, float* scratch, void* stream_) {
-    return vn_forward_impl(P, prepared, nullptr, s->obs_key, s->eval_obs, s->eval_slots, s->max_nodes,
+    // the requests of the last tm_sim_step launch, drawn from its dense list (s->eval_parity = that launch's)
+    const ReqList rq{reinterpret_cast<const int2*>(s->eval_list), s->eval_cnt, s->eval_parity, TM_EVAL_SEGS(s->n_games), s->eval_slots};
+    return vn_forward_impl(P, prepared, nullptr, s->obs_key, rq, s->max_nodes,
                            s->n_games * s->eval_slots, s->eval_v, s->eval_var, scratch, (hipStream_t)stream_);
 }
 

@@ -24,6 +24,14 @@ PARAM_ORDER = ["head.conv1.weight", "head.conv1.bias", "head.conv2.weight", "hea
                "out_ubound", "out_lbound"]
 EXP_PATH = "./pytorch_model/"
 variance_bound = 1e-1
+_epoch = [0]
+
+
+def next_weights_epoch():
+    """A number no other set of evaluator weights in this process has had (>= 1): the tree engine files the evaluator's output
+    per observation under it (tm_store::obs_eval) and uses only what was filed under the current one."""
+    _epoch[0] += 1
+    return _epoch[0]
 
 
 class Net(nn.Module):
@@ -56,6 +64,7 @@ class Model_VV:
         self.backend = backend
         self._flat = None
         self._prepared = None
+        self.weights_epoch = next_weights_epoch()
         self._scratch = None         # "hip": zero-filled rows of SCRATCH_MFMA floats (k_vn_fc1 keeps a counter per 32 states in them)
         self._scratch_plain = None   # "hip_plain": its own buffer - never handed to the matrix-core kernels
 
@@ -92,6 +101,7 @@ class Model_VV:
         self.model.eval()
         self._flat = None
         self._prepared = None
+        self.weights_epoch = next_weights_epoch()
         return res
 
     def load(self, filename=EXP_PATH + "model_checkpoint"):
@@ -110,6 +120,7 @@ class Model_VV:
             print("Checkpoint not found, using default model", flush=True)
         self._flat = None
         self._prepared = None
+        self.weights_epoch = next_weights_epoch()
 
     def save(self, filename=EXP_PATH + "model_checkpoint", verbose=True):
         if verbose:
@@ -130,6 +141,7 @@ class Model_VV:
             off += n
         self._flat = None
         self._prepared = None
+        self.weights_epoch = next_weights_epoch()
 
     def flat_params(self):
         if self._flat is None:

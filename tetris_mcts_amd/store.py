@@ -10,12 +10,13 @@ import torch
 
 from . import _lib
 
-SIM_BACKUP, SIM_FRONT, SIM_GC_FULL = 1, 2, 4
+SIM_BACKUP, SIM_FRONT, SIM_GC_FULL, SIM_EVAL_NEEDED = 1, 2, 4, 8
 KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA, KIND_VANILLA_C, KIND_DIST = 0, 1, 2, 3, 4, 5, 6
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18, MAX_TRACE=19, N_DROPPED=25,
           CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_SLICES=38,
-          SIM_TARGET=40, SIM_STARTED=41, CYC_VERIFY=42, FIRST_MISS=28, PREFIX_SUM=29, N_WALK_MISS=43, POOL_FULL=44, GC_IN_MOVE=45, GC_REQ_AT=46)
+          SIM_TARGET=40, SIM_STARTED=41, CYC_VERIFY=42, FIRST_MISS=28, PREFIX_SUM=29, N_WALK_MISS=43, POOL_FULL=44, GC_IN_MOVE=45, GC_REQ_AT=46,
+          LEAF_OBS=47, N_EVAL_SKIP=48, N_EVAL_CACHED=49)
 
 _nq_cache = {}
 
@@ -86,6 +87,11 @@ class TreeStore:
             replay_count=z(G),
             mt_state=z(G if kind in (KIND_VANILLA, KIND_VANILLA_C) else 1, 625),
         )
+        # the dense request list of every launch, and (single-leaf kinds with an observation projection) the evaluator's output
+        # per observation - include/tetris_mcts_hip.h tm_store::eval_list / obs_eval
+        self.t["eval_list"] = z(G * eval_slots, 2)
+        self.t["eval_cnt"] = z(G, 2)
+        self.t["obs_eval"] = z(G, N, 4, dtype=torch.float32) if kind in (KIND_VALUESIM, KIND_CPPAGENT) else None
         self.t["nq_table"] = norm_quantile_table(nq_size, dev)
         # TM_KIND_DIST only: the nodes' value distributions, the evaluator's output, norm_quantile in double
         is_dist = kind == KIND_DIST
@@ -104,8 +110,9 @@ class TreeStore:
         s.gamma = float(gamma)
         for name, typ in _lib.TmStore._fields_[16:]:
             if typ is C.c_void_p:
-                setattr(s, name, self.t[name].data_ptr())
+                setattr(s, name, self.t[name].data_ptr() if self.t[name] is not None else None)
         s.dist_bins, s.dist_vmin, s.dist_vmax = int(dist_bins), float(dist_range[0]), float(dist_range[1])
+        s.eval_parity, s.eval_epoch = 0, 0
         self.s = s
         self.stats_buf = torch.zeros(G, 3, 7, dtype=torch.float32, device=dev)
         self.action_buf = torch.zeros(G, dtype=torch.int32, device=dev)
@@ -126,7 +133,7 @@ class TreeStore:
         self.t["mt_state"].copy_(torch.from_numpy(arr.view(np.int32)))
 
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in self.t.values())
+        return sum(t.numel() * t.element_size() for t in self.t.values() if t is not None)
 
     # ---- tree agent entry points ----
     def set_root_games(self, games):
@@ -186,6 +193,8 @@ class TreeStore:
             P = prep = scr = C.c_void_p(0)
         else:
             P, prep, scr = model.hip_buffers(self.n_games * self.eval_slots)
+            # the version of the weights the evaluator runs on: what was filed per observation under another one is not used
+            self.L.tm_search_set_epoch(h, int(getattr(model, "weights_epoch", 0)))
         _lib.check(self.L.tm_search_run(h, int(sims), P, prep, scr, _stream()), "tm_search_run")
 
     def search_stats(self, n_sub=1, ev_every=0, reset=True):
@@ -200,6 +209,8 @@ class TreeStore:
         return dict(zip(keys, list(out)))
 
     def sim_step(self, flags):
+        if flags & SIM_FRONT:
+            self.s.eval_parity ^= 1      # the dense request list: a launch appends under the other parity (tm_store::eval_list)
         _lib.check(self.L.tm_sim_step(C.byref(self.s), int(flags), _stream()), "tm_sim_step")
 
     def render_eval(self):
