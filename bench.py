@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STATE = 3803136            # conv1 82,944 + conv2 1,769,472 + conv3 1,032,192 + fc1 917,504 + fc_out 1,024
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
-PMC_FILE = os.path.join("profiles", "r0[34]_pmc_traffic*.json")      # one file per profiled command line (workload_key)
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic*.json")      # one file per profiled command line (workload_key)
 
 
 def pmc_traffic(kernels, workload_key, fetch_scale=1.0):
