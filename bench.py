@@ -67,6 +67,310 @@ def bytes_per_sim(mean_trace_len, k_eval):
     return 204.0 * mean_trace_len - 144.0 + 1296.0 + 1000.0 * k_eval
 
 
+AGENTS = {"ValueSim": 1, "ValueSimLP": 2, "DistValueSim": 4, "Vanilla": 0}     # -> BASELINE.json configs[i]
+
+
+def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx):
+    """One agent's windows on this rank's games: `warmup` untimed moves, `steps` timed ones (barrier + synchronize on both
+    sides, max over ranks, counters summed over ranks), optionally a second window later in the same games.  Returns the fields
+    of a bench line (rank 0; None elsewhere) and the model."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from tetris_mcts_amd import agents, store as st, dist as tdist
+    from tetris_mcts_amd.model import Model_VV
+    from tetris_mcts_amd.pyTetris import Tetris
+    rank, world = ctx["rank"], ctx["world"]
+    G, NS = args.games, args.split
+    EV_EVERY = int(os.environ.get("TM_BENCH_EVENT_EVERY", "16"))
+    env_args = ((20, 10), 1, 0, 0)
+    is_dist, is_vanilla = name == "DistValueSim", name == "Vanilla"
+    max_nodes = args.max_nodes
+    kw = {}
+    if is_dist:
+        # BASELINE configs[4]: the distributional head (model/model_distributional.py Net, 50 atoms over [0, 5000)), random init
+        from tetris_mcts_amd.model_distributional import Model_Dist
+        model = Model_Dist(atoms=50, seed=0, backend=args.backend)
+        assert not args.online, "the online leg of the distributional agent is scripts/selfplay_online.py --agent DistValueSim"
+        kw["model"] = model
+    elif is_vanilla:
+        # BASELINE configs[0]: plain UCT, random rollouts to the end of the game inside the tree kernel (CPython MT19937 per
+        # game), no network; the reference's pool of 500 000 nodes is never approached at 100 simulations a move
+        model = None
+        max_nodes = min(max_nodes, args.vanilla_max_nodes)
+        kw["random_seed"] = 0
+    else:
+        model = Model_VV(backend=args.backend, seed=0)  # model_vv.Net() under torch.manual_seed(0) (random init)
+        kw["model"] = model
+    game = Tetris(*env_args, seed=tdist.game_seeds(20260925, G, rank), n_games=G)     # game g of rank r = game r*G + g of the job
+    if not is_vanilla:
+        kw.update(dict(online=True, min_visits_to_store=10, replay_cap=16384) if args.online else dict(online=False))
+    agent = getattr(agents, name)(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=max_nodes,
+                                  n_sub=NS, ev_every=EV_EVERY, gc_slice_cycles=args.gc_slice_cycles, gc_spec_nodes=args.gc_spec_nodes,
+                                  **kw)
+    agent.update_root(game)
+    torch.cuda.synchronize()
+    S = agent.store
+    dev = S.device
+    py_loop = agent.search_model() is False     # the launch loop runs in Python (an evaluator that is not a HIP net)
+    K = S.eval_slots
+    NS = agent.n_sub
+    tally = dict(episodes=0, lines=0)
+    gather = dict(ms=0.0, tuples=0, bytes=0, calls=0, checksum_ok=True)
+
+    def one_step(timed):
+        action = agent.play()      # mcts(sims) + get_action (games whose reachable tree outgrew the pool restart with an empty tree)
+        game.play(action)
+        agent.update_root(game)   # reads game.end: one small host sync per move, as the reference's loop has
+        ended = np.atleast_1d(game.end)
+        if ended.any():
+            if timed:
+                tally["episodes"] += int(ended.sum())
+                tally["lines"] += int(np.atleast_1d(game.line_clears)[ended].sum())
+            game.reset("ended")
+            agent.update_root(game)
+        if args.online:
+            # the one exchange step of the job: this rank's freshly harvested tuples -> every rank (RCCL all-gather)
+            t0 = time.perf_counter()
+            keys, stats = S.replay()
+            S.t["replay_count"].zero_()
+            local_sum = keys.to(torch.int64).sum() + stats.view(torch.int32).to(torch.int64).sum()
+            n_local = keys.shape[0]
+            ka, sa = tdist.all_gather_tuples(keys.view(torch.int32), stats)
+            tot = torch.stack([local_sum, torch.tensor(n_local, device=dev, dtype=torch.int64)])
+            if dist.is_initialized():
+                dist.all_reduce(tot)
+            torch.cuda.synchronize()
+            if timed:
+                gather["ms"] += 1e3 * (time.perf_counter() - t0)
+                gather["tuples"] += int(ka.shape[0])
+                gather["bytes"] += int(ka.shape[0]) * 64
+                gather["calls"] += 1
+                # the gathered multiset is the union of the ranks' harvests: same count, same word sum
+                got = ka.to(torch.int64).sum() + sa.view(torch.int32).to(torch.int64).sum()
+                gather["checksum_ok"] &= bool(int(tot[1].item()) == int(ka.shape[0]) and int(tot[0].item()) == int(got.item()))
+
+    CNT = ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL", "N_GC", "GC_SLICES", "N_DROPPED", "N_POOL_RESET", "PREFIX_SUM",
+           "N_EVAL_SKIP", "N_EVAL_CACHED")
+
+    def counters():
+        return {k: S.counter(k) for k in CNT}
+
+    def measure(n_steps):
+        tally["episodes"], tally["lines"] = 0, 0
+        torch.cuda.synchronize()
+        S.search_stats(NS, EV_EVERY, reset=True)
+        if py_loop:
+            agent.loop_stats(reset=True)
+        if world > 1:
+            dist.barrier()
+        c0 = counters()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            one_step(True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        c1 = counters()
+        ss = S.search_stats(NS, EV_EVERY, reset=False) or {}
+        if py_loop:      # the launch loop ran in Python (TreeAgent.mcts): its own sampled events
+            ss = agent.loop_stats(reset=True)
+        err = int((S.errors() != 0).sum().item())
+        d = {k: c1[k] - c0[k] for k in c0}
+        tot = torch.tensor([elapsed, d["N_EXPAND"], d["N_SIMS"], d["TRACE_SUM"], d["N_EVAL"], tally["episodes"], tally["lines"], err,
+                            d["N_GC"], d["GC_SLICES"], d["N_DROPPED"], ss.get("catchup_launches", 0.0), d["N_POOL_RESET"],
+                            ss.get("gc_launches", 0.0), d["PREFIX_SUM"], d["N_EVAL_SKIP"], d["N_EVAL_CACHED"]], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = tot[:1].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            tot[0] = tmax[0]
+        keys = ("elapsed", "n_exp", "n_sims", "tr_sum", "n_eval", "episodes", "lines", "err", "n_gc", "gc_slices", "dropped",
+                "catchup", "pool_resets", "gc_launches", "prefix_sum", "n_skip", "n_cached")
+        r = dict(zip(keys, [float(x) for x in tot.cpu()]))
+        r["ss"], r["steps"] = ss, n_steps
+        return r
+
+    def kernel_figures(r):
+        """Per-launch durations of the two halves of a simulation step.  HIP events around the whole launch loop of every move
+        give the time per simulation (evaluator + tree kernel + launch gaps); events around every EV_EVERY-th simulation give
+        the two intervals themselves (`*_event_ms`, each carrying the cost of its own event records, so their plain sum
+        slightly exceeds the loop's time per simulation); the figures the roofline uses are the measured intervals scaled by
+        one common factor so that they add up to the loop's time per simulation."""
+        ss = r["ss"]
+        if py_loop and ss.get("timed"):      # Python-driven loop: the sampled intervals as they are
+            nn_ev, tree_ev = ss["nn_ms_sum"] / ss["timed"], ss["tree_ms_sum"] / ss["timed"]
+            return dict(nn_ms=nn_ev, tree_ms=tree_ev, nn_event_ms=nn_ev, tree_event_ms=tree_ev, per_sim_ms=nn_ev + tree_ev,
+                        timed=int(ss["timed"]))
+        if not ss.get("timed") or not ss.get("loop_sims"):
+            return None
+        nn_ev, tree_ev = ss["nn_ms_sum"] / ss["timed"], ss["tree_ms_sum"] / ss["timed"]
+        per_sim = ss["loop_ms_sum"] / ss["loop_sims"]
+        scale = per_sim / (nn_ev + tree_ev)
+        return dict(nn_ms=nn_ev * scale, tree_ms=tree_ev * scale, nn_event_ms=nn_ev, tree_event_ms=tree_ev, per_sim_ms=per_sim,
+                    timed=int(ss["timed"]))
+
+    for _ in range(warmup):
+        one_step(False)
+    head = measure(steps)
+    max_trace = int(S.t["gs"][:, st.GS["MAX_TRACE"]].max().item())
+    phase_kcycles = {k: float(S.t["gs"][:, st.GS[k]].float().mean().item()) / 1e3
+                     for k in ("CYC_BACK", "CYC_SELECT", "CYC_VERIFY", "CYC_EXPAND", "FIRST_MISS", "TRACE_LEN")}
+    steady = None
+    moves_done = warmup + steps
+    if steady_steps > 0 and not args.online and (world == 1 or args.steady_multi):
+        # the regime self-play lives in: trees fill their pools, games collect garbage every few moves (same games, later)
+        for _ in range(max(0, steady_warmup - moves_done)):
+            one_step(False)
+        first_move = max(steady_warmup, moves_done) + 1
+        steady = measure(steady_steps)
+        steady["first_move"] = first_move
+    store_gib = S.nbytes() / 2**30
+    walk_miss = S.counter("N_WALK_MISS") / max(S.counter("TRACE_SUM"), 1)
+    collective = bool(dist.is_initialized())
+    backend_name = dist.get_backend() if dist.is_initialized() else None
+    del agent, game, S
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None, model
+
+    elapsed, n_exp, n_sims, n_eval = head["elapsed"], head["n_exp"], head["n_sims"], head["n_eval"]
+    mean_len = head["tr_sum"] / max(n_sims, 1.0)
+    workload_key = "%s G=%d sims=%d pool=%d warmup=%d steps=%d split=%d" % (name, G, sims, max_nodes, warmup, steps, NS)
+
+    def gc_block(r):
+        return {"collections": int(r["n_gc"]), "collector_launches_x_games": int(r["gc_slices"]),
+                "launches_per_collection": (r["gc_slices"] / r["n_gc"]) if r["n_gc"] else None,
+                "catchup_launches": int(r["catchup"]), "catchup_launches_per_move": r["catchup"] / r["steps"] / world,
+                "collector_only_launches": int(r["gc_launches"]), "dropped_tuples": int(r["dropped"]),
+                "trees_restarted_pool_outgrown": int(r["pool_resets"])}
+
+    def request_block(r):
+        """what the leaf evaluator was asked for: requests posted to the net, and those the search did without because the
+        backup would not have used the output (identical results: bench.py docstring / DESIGN section 3.3)"""
+        unique = r["n_eval"] + r["n_skip"] + r["n_cached"]
+        return {"posted_to_the_evaluator": int(r["n_eval"]), "per_expansion": r["n_eval"] / max(r["n_exp"], 1.0),
+                "leaf_parallel_children_already_visited_not_posted": int(r["n_skip"]),
+                "single_leaf_observation_evaluated_before_answered_from_cache": int(r["n_cached"]),
+                "fraction_not_posted": (r["n_skip"] + r["n_cached"]) / unique if unique else 0.0}
+
+    what = ("plain UCT with random rollouts inside the tree kernel (no network)" if is_vanilla else
+            "UCT with the distributional head as leaf evaluator" if is_dist else "UCT with value-net leaf evaluation")
+    out = {
+        "metric": "mcts_node_expansions_per_sec",
+        "value": n_exp / elapsed,
+        "unit": "node-expansions/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "%d games/GPU x %d sims/move, %s %s (BASELINE configs[%d]); Tetris 20x10 app=1 guideline scoring 7-bag; "
+                        "node pool %d/game%s" % (G, sims, name, what, AGENTS[name], max_nodes,
+                                                 "" if is_vanilla else "; network random init under manual_seed(0)"),
+            "workload_key": workload_key,
+            "games_per_gpu": G, "sims_per_move": sims, "agent": name, "max_nodes": max_nodes,
+            "valuenet_backend": None if is_vanilla else args.backend, "sub_batches": NS, "online": bool(args.online),
+            "gc_slice_cycles": args.gc_slice_cycles, "gc_spec_nodes": args.gc_spec_nodes,
+        },
+        "sims_per_sec": n_sims / elapsed,
+        "child_steps_per_sec": 7.0 * n_exp / elapsed,
+        "evaluated_states_per_sec": n_eval / elapsed,
+        "requests": request_block(head),
+        "mean_trace_len": mean_len,
+        "max_trace_len": max_trace,
+        "walk_levels_taken_over_from_the_previous_walk": head["prefix_sum"] / max(head["tr_sum"], 1.0),
+        "episodes_finished": int(head["episodes"]),
+        "lines_cleared_per_episode": (head["lines"] / head["episodes"]) if head["episodes"] else None,
+        "lines_note": None if head["episodes"] else "no episode ends inside the timed window (random-init network, moves %d-%d "
+                      "of every game); the learning curve (lines cleared per episode vs training round) is "
+                      "scripts/selfplay_online.py -> profiles/*_online_learning.jsonl" % (warmup + 1, warmup + steps),
+        "error_games": int(head["err"]),
+        "walk_mispredicted_levels": walk_miss,
+        "gc": gc_block(head),
+        "store_gib_per_gpu": store_gib,
+        "last_sim_phase_kcycles": phase_kcycles,
+    }
+    if steady is not None:
+        kf = kernel_figures(steady)
+        out["steady_state"] = {
+            "what": "the same games later on: moves %d-%d, node pools full, every game collects garbage every few moves "
+                    "(reported beside the headline window, which SURVEY.md 8(d) defines as moves %d-%d)"
+                    % (steady["first_move"], steady["first_move"] + steady["steps"] - 1, warmup + 1, warmup + steps),
+            "value": steady["n_exp"] / steady["elapsed"], "unit": "node-expansions/s",
+            "ms_per_step": 1e3 * steady["elapsed"] / steady["steps"], "steps": steady["steps"],
+            "sims_per_sec": steady["n_sims"] / steady["elapsed"],
+            "mean_trace_len": steady["tr_sum"] / max(steady["n_sims"], 1.0),
+            "episodes_finished": int(steady["episodes"]),
+            "lines_cleared_per_episode": (steady["lines"] / steady["episodes"]) if steady["episodes"] else None,
+            "requests": request_block(steady),
+            "error_games": int(steady["err"]), "gc": gc_block(steady),
+            "tree_kernel_ms": kf["tree_ms"] if kf else None, "value_net_ms": kf["nn_ms"] if kf else None,
+        }
+    if args.online:
+        out["exchange"] = {"what": "all-gather of the (packed observation, value, variance, visit) tuples harvested at GC, "
+                                   "once per move (tetris_mcts_amd/dist.py all_gather_tuples, backend nccl = RCCL)",
+                           "backend": backend_name, "collective_ran": collective,
+                           "calls": gather["calls"], "tuples": gather["tuples"], "bytes": gather["bytes"],
+                           "ms_total": gather["ms"], "multiset_check": gather["checksum_ok"]}
+    kf = kernel_figures(head)
+    if kf:
+        nn_ms, tree_ms = kf["nn_ms"], kf["tree_ms"]
+        Gs = G / NS
+        evals_per_launch = n_eval / max(n_sims, 1.0) * Gs
+        flops = (FLOP_PER_STATE_DIST if is_dist else FLOP_PER_STATE) * evals_per_launch
+        a_tf = flops / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
+        # SURVEY 8(d): k_eval = the states rendered for the evaluator per expansion (what was really posted)
+        bps = bytes_per_sim_dist(mean_len) if is_dist else bytes_per_sim(mean_len, n_eval / max(n_exp, 1.0))
+        a_gbs = bps * Gs / (tree_ms * 1e-3) / 1e9
+        note = ("bytes/launch from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line); null when "
+                "no file was recorded for this workload" % PMC_FILE)
+        tnote = ("HIP events on the launch stream: around the whole launch loop of every move (%.4f ms per simulation = evaluator "
+                 "+ tree kernel + launch gaps) and around every %d-th simulation (measured intervals %.4f / %.4f ms = "
+                 "avg_launch_event_ms, each carrying its own event records); avg_launch_ms = the measured intervals scaled by one "
+                 "factor to add up to the loop's time per simulation, so avg_launch_ms x %d simulations <= ms_per_step.  The "
+                 "rocprofv3 kernel trace of the same command is profiles/r04_kernel_stats_*.csv"
+                 % (kf["per_sim_ms"], EV_EVERY, kf["nn_event_ms"], kf["tree_event_ms"], sims))
+        nn_roof = {"kernel": (("distributional head (k_dn_conv + k_dn_fc: render, two convolutions, two linear layers and the softmax on the fp32 matrix cores), per launch of %d leaf slots"
+                               if args.backend == "hip" else "distributional head (model_distributional.Net on PyTorch-ROCm: MIOpen / rocBLAS kernels + the request render), per evaluation of %d leaves")
+                              if is_dist else "value net forward (k_vn_conv + k_vn_fc1 with the output layer folded in), per launch over %d request slots") % int(Gs * K),
+                   "bound": "mfma", "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                   "frac": a_tf / PEAK_F32_MATRIX_TFLOPS,
+                   "states_per_launch": evals_per_launch,
+                   "traffic": pmc_traffic(["tmcts_dn::k_dn_conv", "tmcts_dn::k_dn_fc"] if is_dist else ["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1"],
+                                          workload_key, 2.0) if args.backend == "hip" else None,
+                   "traffic_note": note + "; FETCH_SIZE x2 (wide streams)",
+                   "avg_launch_ms": nn_ms, "avg_launch_event_ms": kf["nn_event_ms"], "launches_timed": kf["timed"],
+                   "events_every": EV_EVERY, "timing_note": tnote}
+        tree_roof = {"kernel": "k_sim_step (backup+select+expand%s), per launch of %d games" % (" + rollout" if is_vanilla else "", int(Gs)), "bound": "hbm",
+                     "achieved": a_gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBPS,
+                     "traffic": pmc_traffic(["tmcts::k_sim_step<%s>" % ("true" if is_vanilla else "false")], workload_key),
+                     "traffic_note": note + " (narrow scattered accesses: no gfx950 correction)",
+                     "avg_launch_ms": tree_ms, "avg_launch_event_ms": kf["tree_event_ms"], "algorithmic_bytes_per_sim": bps,
+                     "launches_timed": kf["timed"], "events_every": EV_EVERY, "timing_note": tnote}
+        if is_vanilla:
+            out["roofline"] = tree_roof
+        else:
+            out["roofline"] = nn_roof if nn_ms >= tree_ms else tree_roof
+            out["roofline_other"] = tree_roof if nn_ms >= tree_ms else nn_roof
+    return out, model
+
+
+def compact(line):
+    """a secondary config's line inside the headline's: the figures, not the prose"""
+    keep = ("value", "unit", "steps", "warmup", "ms_per_step", "sims_per_sec", "evaluated_states_per_sec", "requests", "mean_trace_len",
+            "episodes_finished", "lines_cleared_per_episode", "error_games", "store_gib_per_gpu", "cpu_baseline")
+    out = {k: line[k] for k in keep if k in line}
+    out["workload"] = line["config"]["workload"]
+    for rk in ("roofline", "roofline_other"):
+        if rk in line:
+            out[rk] = {k: line[rk][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+                                                "avg_launch_event_ms", "states_per_launch", "algorithmic_bytes_per_sim") if k in line[rk]}
+    return out
+
+
 def main():
     global np
     ap = argparse.ArgumentParser()
@@ -74,9 +378,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)     # 5 warm-up moves, then 20 timed moves
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--games", type=int, default=4096, help="games per GPU")
-    ap.add_argument("--sims", type=int, default=500)
-    ap.add_argument("--agent", default="ValueSim", choices=["ValueSim", "ValueSimLP", "DistValueSim"])
+    ap.add_argument("--sims", type=int, default=None, help="simulations per move (default: 500; Vanilla 100, BASELINE configs[0])")
+    ap.add_argument("--agent", default="ValueSim", choices=sorted(AGENTS))
     ap.add_argument("--max-nodes", type=int, default=100000)
+    ap.add_argument("--vanilla-max-nodes", type=int, default=20000, help="node pool per game of the Vanilla lines")
     ap.add_argument("--backend", default="hip", choices=["hip", "torch"])
     ap.add_argument("--split", type=int, default=int(os.environ.get("TM_BENCH_SPLIT", "1")),
                     help="sub-batches of the rank's games on separate HIP streams (one sub-batch's tree kernel runs "
@@ -88,6 +393,9 @@ def main():
     ap.add_argument("--steady-warmup", type=int, default=75, help="the steady-state window starts after this many moves")
     ap.add_argument("--steady-steps", type=int, default=20, help="moves of the second, steady-state window (0: none)")
     ap.add_argument("--steady-multi", action="store_true", help="measure the steady-state window in multi-GPU runs too")
+    ap.add_argument("--others", default="auto", choices=["auto", "none", "all"],
+                    help="short lines of the other BASELINE configs (ValueSimLP, DistValueSim at 1000 sims, Vanilla at 100 sims) "
+                    "inside the headline's; auto = when this is the default single-GPU ValueSim run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the N-process CPU baseline (0: all host cores, at most 128)")
@@ -113,256 +421,39 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    from tetris_mcts_amd import agents, store as st, dist as tdist
-    from tetris_mcts_amd.model import Model_VV
-    from tetris_mcts_amd.pyTetris import Tetris
-
-    G, sims, NS = args.games, args.sims, args.split
-    EV_EVERY = int(os.environ.get("TM_BENCH_EVENT_EVERY", "16"))
-    env_args = ((20, 10), 1, 0, 0)
-    is_dist = args.agent == "DistValueSim"
-    if is_dist:
-        # BASELINE configs[4]: the distributional head (model/model_distributional.py Net, 50 atoms over [0, 5000)), random init
-        from tetris_mcts_amd.model_distributional import Model_Dist
-        model = Model_Dist(atoms=50, seed=0, backend=args.backend)
-        assert not args.online, "the distributional agent has no online leg (DESIGN.md section 8)"
-    else:
-        model = Model_VV(backend=args.backend, seed=0)  # model_vv.Net() under torch.manual_seed(0) (random init)
-    game = Tetris(*env_args, seed=tdist.game_seeds(20260925, G, rank), n_games=G)     # game g of rank r = game r*G + g of the job
-    okw = dict(online=True, min_visits_to_store=10, replay_cap=16384) if args.online else dict(online=False)
-    agent = getattr(agents, args.agent)(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=args.max_nodes,
-                                        model=model, n_sub=NS, ev_every=EV_EVERY, gc_slice_cycles=args.gc_slice_cycles, gc_spec_nodes=args.gc_spec_nodes,
-                                        **okw)
-    agent.update_root(game)
-    torch.cuda.synchronize()
-    S = agent.store
-    dev = S.device
-    py_loop = agent.search_model() is False     # the launch loop runs in Python (an evaluator that is not a HIP net)
-    K = S.eval_slots
-    NS = agent.n_sub
-    episodes, lines = 0, 0
-    gather = dict(ms=0.0, tuples=0, bytes=0, calls=0, checksum_ok=True)
-
-    def one_step(timed):
-        nonlocal episodes, lines
-        action = agent.play()      # mcts(sims) + get_action (games whose reachable tree outgrew the pool restart with an empty tree)
-        game.play(action)
-        agent.update_root(game)   # reads game.end: one small host sync per move, as the reference's loop has
-        ended = np.atleast_1d(game.end)
-        if ended.any():
-            if timed:
-                episodes += int(ended.sum())
-                lines += int(np.atleast_1d(game.line_clears)[ended].sum())
-            game.reset("ended")
-            agent.update_root(game)
-        if args.online:
-            # the one exchange step of the job: this rank's freshly harvested tuples -> every rank (RCCL all-gather)
-            t0 = time.perf_counter()
-            keys, stats = S.replay()
-            S.t["replay_count"].zero_()
-            local_sum = keys.to(torch.int64).sum() + stats.view(torch.int32).to(torch.int64).sum()
-            n_local = keys.shape[0]
-            ka, sa = tdist.all_gather_tuples(keys.view(torch.int32), stats)
-            tot = torch.stack([local_sum, torch.tensor(n_local, device=dev, dtype=torch.int64)])
-            if dist.is_initialized():
-                dist.all_reduce(tot)
-            torch.cuda.synchronize()
-            if timed:
-                gather["ms"] += 1e3 * (time.perf_counter() - t0)
-                gather["tuples"] += int(ka.shape[0])
-                gather["bytes"] += int(ka.shape[0]) * 64
-                gather["calls"] += 1
-                # the gathered multiset is the union of the ranks' harvests: same count, same word sum
-                got = ka.to(torch.int64).sum() + sa.view(torch.int32).to(torch.int64).sum()
-                gather["checksum_ok"] &= bool(int(tot[1].item()) == int(ka.shape[0]) and int(tot[0].item()) == int(got.item()))
-
-    def counters():
-        return {k: S.counter(k) for k in ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL", "N_GC", "GC_SLICES", "N_DROPPED", "N_POOL_RESET", "PREFIX_SUM")}
-
-    def measure(n_steps):
-        """Time exactly n_steps moves of every game (barrier + synchronize on both sides, max over ranks); counters are
-        summed over ranks."""
-        nonlocal episodes, lines
-        episodes, lines = 0, 0
-        torch.cuda.synchronize()
-        S.search_stats(NS, EV_EVERY, reset=True)
-        if py_loop:
-            agent.loop_stats(reset=True)
-        if world > 1:
-            dist.barrier()
-        c0 = counters()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_steps):
-            one_step(True)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        c1 = counters()
-        ss = S.search_stats(NS, EV_EVERY, reset=False) or {}
-        if py_loop:      # the launch loop ran in Python (TreeAgent.mcts): its own sampled events
-            ss = agent.loop_stats(reset=True)
-        err = int((S.errors() != 0).sum().item())
-        d = {k: c1[k] - c0[k] for k in c0}
-        tot = torch.tensor([elapsed, d["N_EXPAND"], d["N_SIMS"], d["TRACE_SUM"], d["N_EVAL"], episodes, lines, err,
-                            d["N_GC"], d["GC_SLICES"], d["N_DROPPED"], ss.get("catchup_launches", 0.0), d["N_POOL_RESET"],
-                            ss.get("gc_launches", 0.0), d["PREFIX_SUM"]], dtype=torch.float64, device=dev)
-        if world > 1:
-            tmax = tot[:1].clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            tot[0] = tmax[0]
-        keys = ("elapsed", "n_exp", "n_sims", "tr_sum", "n_eval", "episodes", "lines", "err", "n_gc", "gc_slices", "dropped",
-                "catchup", "pool_resets", "gc_launches", "prefix_sum")
-        r = dict(zip(keys, [float(x) for x in tot.cpu()]))
-        r["ss"], r["steps"] = ss, n_steps
-        return r
-
-    def kernel_figures(r):
-        """Per-launch durations of the two halves of a simulation step.  HIP events around every EV_EVERY-th simulation
-        give the SPLIT between value net and tree kernel; the events around the whole launch loop of every move give the
-        time per simulation the two must add up to (the sampled intervals each carry the cost of their own event records,
-        so their plain sum slightly exceeds the step)."""
-        ss = r["ss"]
-        if py_loop and ss.get("timed"):      # Python-driven loop: the sampled intervals as they are
-            nn_ev, tree_ev = ss["nn_ms_sum"] / ss["timed"], ss["tree_ms_sum"] / ss["timed"]
-            return dict(nn_ms=nn_ev, tree_ms=tree_ev, nn_event_ms=nn_ev, tree_event_ms=tree_ev, per_sim_ms=nn_ev + tree_ev,
-                        timed=int(ss["timed"]))
-        if not ss.get("timed") or not ss.get("loop_sims"):
-            return None
-        nn_ev, tree_ev = ss["nn_ms_sum"] / ss["timed"], ss["tree_ms_sum"] / ss["timed"]
-        per_sim = ss["loop_ms_sum"] / ss["loop_sims"]
-        scale = per_sim / (nn_ev + tree_ev)
-        return dict(nn_ms=nn_ev * scale, tree_ms=tree_ev * scale, nn_event_ms=nn_ev, tree_event_ms=tree_ev, per_sim_ms=per_sim,
-                    timed=int(ss["timed"]))
-
-    for _ in range(args.warmup):
-        one_step(False)
-    head = measure(args.steps)
-    max_trace = int(S.t["gs"][:, st.GS["MAX_TRACE"]].max().item())
-    phase_kcycles = {k: float(S.t["gs"][:, st.GS[k]].float().mean().item()) / 1e3
-                     for k in ("CYC_BACK", "CYC_SELECT", "CYC_VERIFY", "CYC_EXPAND", "FIRST_MISS", "TRACE_LEN")}
-    steady = None
-    moves_done = args.warmup + args.steps
-    if args.steady_steps > 0 and not args.online and (world == 1 or args.steady_multi):
-        # the regime self-play lives in: trees fill their pools, games collect garbage every few moves (same games, later)
-        for _ in range(max(0, args.steady_warmup - moves_done)):
-            one_step(False)
-        first_move = max(args.steady_warmup, moves_done) + 1
-        steady = measure(args.steady_steps)
-        steady["first_move"] = first_move
-
-    if rank != 0:
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        return
-    elapsed, n_exp, n_sims, n_eval = head["elapsed"], head["n_exp"], head["n_sims"], head["n_eval"]
-    mean_len = head["tr_sum"] / max(n_sims, 1.0)
-    cfg_idx = {"ValueSim": 1, "ValueSimLP": 2, "DistValueSim": 4}[args.agent]
-    workload_key = "%s G=%d sims=%d pool=%d warmup=%d steps=%d split=%d" % (args.agent, G, sims, args.max_nodes,
-                                                                           args.warmup, args.steps, NS)
-
-    def gc_block(r):
-        return {"collections": int(r["n_gc"]), "collector_launches_x_games": int(r["gc_slices"]),
-                "launches_per_collection": (r["gc_slices"] / r["n_gc"]) if r["n_gc"] else None,
-                "catchup_launches": int(r["catchup"]), "catchup_launches_per_move": r["catchup"] / r["steps"] / world,
-                "collector_only_launches": int(r["gc_launches"]), "dropped_tuples": int(r["dropped"]),
-                "trees_restarted_pool_outgrown": int(r["pool_resets"])}
-
-    out = {
-        "metric": "mcts_node_expansions_per_sec",
-        "value": n_exp / elapsed,
-        "unit": "node-expansions/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {
-            "workload": "%d games/GPU x %d sims/move, %s UCT with value-net leaf evaluation (BASELINE configs[%d]); "
-                        "Tetris 20x10 app=1 guideline scoring 7-bag; node pool %d/game; Net() random init manual_seed(0)"
-                        % (G, sims, args.agent, cfg_idx, args.max_nodes),
-            "workload_key": workload_key,
-            "games_per_gpu": G, "sims_per_move": sims, "agent": args.agent, "max_nodes": args.max_nodes,
-            "valuenet_backend": args.backend, "sub_batches": NS, "online": bool(args.online),
-            "gc_slice_cycles": args.gc_slice_cycles, "gc_spec_nodes": args.gc_spec_nodes,
-        },
-        "sims_per_sec": n_sims / elapsed,
-        "child_steps_per_sec": 7.0 * n_exp / elapsed,
-        "evaluated_states_per_sec": n_eval / elapsed,
-        "mean_trace_len": mean_len,
-        "max_trace_len": max_trace,
-        "walk_levels_taken_over_from_the_previous_walk": head["prefix_sum"] / max(head["tr_sum"], 1.0),
-        "episodes_finished": int(head["episodes"]),
-        "lines_cleared_per_episode": (head["lines"] / head["episodes"]) if head["episodes"] else None,
-        "lines_note": None if head["episodes"] else "no episode ends inside the timed window (random-init network, moves %d-%d "
-                      "of every game); the learning curve (lines cleared per episode vs training round) is "
-                      "scripts/selfplay_online.py -> profiles/*_online_learning.jsonl" % (args.warmup + 1, args.warmup + args.steps),
-        "error_games": int(head["err"]),
-        "walk_mispredicted_levels": S.counter("N_WALK_MISS") / max(S.counter("TRACE_SUM"), 1),
-        "gc": gc_block(head),
-        "store_gib_per_gpu": S.nbytes() / 2**30,
-        "last_sim_phase_kcycles": phase_kcycles,
-    }
-    if steady is not None:
-        kf = kernel_figures(steady)
-        out["steady_state"] = {
-            "what": "the same games later on: moves %d-%d, node pools full, every game collects garbage every few moves "
-                    "(reported beside the headline window, which SURVEY.md 8(d) defines as moves %d-%d)"
-                    % (steady["first_move"], steady["first_move"] + steady["steps"] - 1, args.warmup + 1, args.warmup + args.steps),
-            "value": steady["n_exp"] / steady["elapsed"], "unit": "node-expansions/s",
-            "ms_per_step": 1e3 * steady["elapsed"] / steady["steps"], "steps": steady["steps"],
-            "sims_per_sec": steady["n_sims"] / steady["elapsed"],
-            "mean_trace_len": steady["tr_sum"] / max(steady["n_sims"], 1.0),
-            "error_games": int(steady["err"]), "gc": gc_block(steady),
-            "tree_kernel_ms": kf["tree_ms"] if kf else None, "value_net_ms": kf["nn_ms"] if kf else None,
-        }
-    if args.online:
-        out["exchange"] = {"what": "all-gather of the (packed observation, value, variance, visit) tuples harvested at GC, "
-                                   "once per move (tetris_mcts_amd/dist.py all_gather_tuples, backend nccl = RCCL)",
-                           "backend": dist.get_backend() if dist.is_initialized() else None,
-                           "collective_ran": bool(dist.is_initialized()),
-                           "calls": gather["calls"], "tuples": gather["tuples"], "bytes": gather["bytes"],
-                           "ms_total": gather["ms"], "multiset_check": gather["checksum_ok"]}
-    kf = kernel_figures(head)
-    if kf:
-        nn_ms, tree_ms = kf["nn_ms"], kf["tree_ms"]
-        Gs = G / NS
-        evals_per_launch = n_eval / max(n_sims, 1.0) * Gs
-        flops = (FLOP_PER_STATE_DIST if is_dist else FLOP_PER_STATE) * evals_per_launch
-        a_tf = flops / (nn_ms * 1e-3) / 1e12
-        bps = bytes_per_sim_dist(mean_len) if is_dist else bytes_per_sim(mean_len, 1 if args.agent == "ValueSim" else n_eval / max(n_exp, 1.0))
-        a_gbs = bps * Gs / (tree_ms * 1e-3) / 1e9
-        note = ("bytes/launch from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line); null when "
-                "that file was recorded for another workload" % PMC_FILE)
-        tnote = ("HIP events on the launch stream: around the whole launch loop of every move (%.4f ms per simulation = value "
-                 "net + tree kernel + launch gaps) and around every %d-th simulation for the split between the two (raw "
-                 "sampled intervals %.4f / %.4f ms, each carrying its own event records); avg_launch_ms x %d simulations <= "
-                 "ms_per_step by construction.  The rocprofv3 kernel trace of the same command is profiles/r03_kernel_stats_*.csv"
-                 % (kf["per_sim_ms"], EV_EVERY, kf["nn_event_ms"], kf["tree_event_ms"], sims))
-        nn_roof = {"kernel": (("distributional head (k_dn_conv + k_dn_fc: render, two convolutions, two linear layers and the softmax on the fp32 matrix cores), per launch of %d leaves"
-                               if args.backend == "hip" else "distributional head (model_distributional.Net on PyTorch-ROCm: MIOpen / rocBLAS kernels + the request render), per evaluation of %d leaves")
-                              if is_dist else "value net forward (k_vn_conv + k_vn_fc1 with the output layer folded in), per launch of %d request slots") % int(Gs * K),
-                   "bound": "mfma", "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                   "frac": a_tf / PEAK_F32_MATRIX_TFLOPS,
-                   "traffic": pmc_traffic(["tmcts_dn::k_dn_conv", "tmcts_dn::k_dn_fc"] if is_dist else ["tmcts_vn::k_vn_conv", "tmcts_vn::k_vn_fc1"],
-                                          workload_key, 2.0) if args.backend == "hip" else None,
-                   "traffic_note": note + "; FETCH_SIZE x2 (wide streams)",
-                   "avg_launch_ms": nn_ms, "launches_timed": kf["timed"], "events_every": EV_EVERY, "timing_note": tnote}
-        tree_roof = {"kernel": "k_sim_step (backup+select+expand), per launch of %d games" % int(Gs), "bound": "hbm",
-                     "achieved": a_gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": a_gbs / PEAK_HBM_GBPS,
-                     "traffic": pmc_traffic(["tmcts::k_sim_step<false>"], workload_key),
-                     "traffic_note": note + " (narrow scattered accesses: no gfx950 correction)",
-                     "avg_launch_ms": tree_ms, "algorithmic_bytes_per_sim": bps, "launches_timed": kf["timed"],
-                     "events_every": EV_EVERY, "timing_note": tnote}
-        out["roofline"] = nn_roof if nn_ms >= tree_ms else tree_roof
-        out["roofline_other"] = tree_roof if nn_ms >= tree_ms else nn_roof
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = ({"value": None, "unit": "node-expansions/s", "cores": 0, "kind": "port",
-                                "sample": "none: the reference has no distributional agent that runs (agents/DistValueSimOnline.py does "
-                                          "not import); the oracle's restatement is a checker, timed nowhere"}
-                               if is_dist else cpu_baseline(args, model))
-    print(json.dumps(out), flush=True)
+    ctx = dict(rank=rank, world=world)
+    sims = args.sims if args.sims is not None else (100 if args.agent == "Vanilla" else 500)
+    args.sims = sims
+    out, model = run_agent(args, args.agent, sims, args.warmup, args.steps, args.steady_warmup, args.steady_steps, ctx)
+    others = {}
+    want_others = args.others == "all" or (args.others == "auto" and world == 1 and args.agent == "ValueSim" and not args.online
+                                           and args.backend == "hip" and args.split == 1)
+    if want_others:
+        # the other configurations of BASELINE.json, short windows, so that the driver's one command line shows them all
+        for name, osims, w, k in (("ValueSimLP", 500, 5, 20), ("DistValueSim", 1000, 2, 5), ("Vanilla", 100, 5, 20)):
+            try:
+                line, omodel = run_agent(args, name, osims, w, k, 0, 0, ctx)
+                if rank == 0:
+                    if not args.no_cpu_baseline and name == "Vanilla":
+                        line["cpu_baseline"] = cpu_baseline_vanilla(args, osims, w, k)
+                    others[name] = compact(line)
+                del omodel
+            except Exception as e:          # a secondary line never costs the headline
+                import traceback
+                others[name] = {"error": repr(e), "trace": traceback.format_exc()[-400:]}
+    if rank == 0:
+        if others:
+            out["other_configs"] = others
+        if world == 1 and not args.no_cpu_baseline:
+            if args.agent == "DistValueSim":
+                out["cpu_baseline"] = {"value": None, "unit": "node-expansions/s", "cores": 0, "kind": "port",
+                                       "sample": "none: the reference has no distributional agent that runs (agents/DistValueSimOnline.py does "
+                                                 "not import); the oracle's restatement is a checker, timed nowhere"}
+            elif args.agent == "Vanilla":
+                out["cpu_baseline"] = cpu_baseline_vanilla(args, sims, args.warmup, args.steps)
+            else:
+                out["cpu_baseline"] = cpu_baseline(args, model)
+        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -570,6 +661,177 @@ def cpu_baseline(args, model):
                                     "the build container: DESIGN.md section 5")
     if errs or errs2:
         out["worker_errors"] = (errs + errs2)[:3]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline of BASELINE configs[0]: "1 game, Vanilla agent, 100 sims/move, random-rollout (no NN) on CPU reference path"
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_worker_vanilla(kind, sims, max_nodes, seconds, seed, q, warm=5, timed=20, stride=1):
+    """One process = one game at a time on one core; moves warm+1 .. warm+timed of fresh games, game after game.
+    kind "reference_c":  the reference's compiled MCTSAgent with evaluator type 1 = a Python random playout (agents/VanillaC.py:5-14)
+         "reference_py": the reference's Python Vanilla (agents/Vanilla.py:17-64), needs the reference sources
+         "port":         the oracle's C restatement of Vanilla (agent_oracle.c kind 4)"""
+    try:
+        import random
+        from oracle import binding as B
+        acc = dict(expansions=0, sims=0, moves=0, seconds=0.0, games=0, rollout_steps=0)
+        t_start = time.perf_counter()
+
+        def play_window(step, count):
+            for _ in range(warm):
+                step()
+            e0 = count()
+            t0 = time.perf_counter()
+            for _ in range(timed):
+                step()
+            acc["seconds"] += time.perf_counter() - t0
+            acc["expansions"] += count() - e0; acc["sims"] += timed * sims; acc["moves"] += timed; acc["games"] += 1
+
+        k = 0
+        while time.perf_counter() - t_start < seconds:
+            gseed = seed + k * stride
+            k += 1
+            random.seed(gseed)
+            if kind == "reference_c":
+                agent_mod = B.load_ref_native("agent")
+                if agent_mod is None:
+                    q.put(None)
+                    return
+                import ctypes
+                ctypes.CDLL("libc.so.6").srand(1)
+                g = B.oracle_pytetris().Tetris((20, 10), 1, 0, 0, gseed)
+                cnt = [0]
+
+                def random_playout(game, cnt=cnt):            # agents/VanillaC.py:5-8; one call per expanded leaf
+                    cnt[0] += 1
+                    while not game.end:
+                        game.play(random.randint(0, 7))
+                    return game.score, 1e5
+                ag = agent_mod.MCTSAgent(sims, max_nodes, True, 0.99, False, random_playout, 1, False)
+                ag.update_root(g)
+
+                def step(g=g, ag=ag):
+                    g.play(int(ag.play()))
+                    ag.update_root(g)
+                    if g.end:
+                        g.reset()
+                        ag.update_root(g)
+                play_window(step, lambda cnt=cnt: cnt[0])
+            elif kind == "reference_py":
+                from oracle import ref_shims
+                ref_shims.install()
+                ref_shims.srand(1)
+                ag = ref_shims.make_agent("Vanilla", sims, max_nodes=max_nodes)
+                cnt = [0]
+                inner = ag.expand
+
+                def counted(game, cnt=cnt, inner=inner):
+                    cnt[0] += 1
+                    return inner(game)
+                ag.expand = counted
+                g = B.oracle_pytetris().Tetris((20, 10), 1, 0, 0, gseed)
+                ag.update_root(g)
+
+                def step(g=g, ag=ag):
+                    g.play(int(ag.play()))
+                    ag.update_root(g)
+                    if g.end:
+                        g.reset()
+                        ag.update_root(g)
+                play_window(step, lambda cnt=cnt: cnt[0])
+            else:
+                g = B.Game(seed=gseed)
+                a = B.Agent(4, max_nodes=max_nodes, gamma=0.99, low=5)
+                a.set_python_random_state(random.Random(gseed).getstate())
+                a.update_root(g)
+
+                def step(g=g, a=a):
+                    g.play(a.play(sims))
+                    a.update_root(g)
+                    if g.end:
+                        g.reset()
+                        a.update_root(g)
+                play_window(step, lambda a=a: a.n_expand)
+        q.put(acc)
+    except Exception as e:
+        import traceback
+        q.put(dict(error=repr(e) + " " + traceback.format_exc()[-300:]))
+
+
+def cpu_baseline_vanilla(args, sims, warm, timed):
+    """configs[0] on this box's host cores, reported only: the reference's compiled agent with its Python playout (VanillaC,
+    `kind` "reference": oracle/_ref travels with the snapshot), the reference's Python Vanilla where its sources are, and the
+    oracle's C restatement (a scalar port: an upper bound of what one core does with this algorithm)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    max_nodes = min(args.max_nodes, args.vanilla_max_nodes)
+
+    def run(kind, nproc, seconds):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_cpu_worker_vanilla, args=(kind, sims, max_nodes, seconds, 20260925 + i, q, warm, timed, nproc))
+                 for i in range(nproc)]
+        for p in procs:
+            p.start()
+        res, deadline = [], time.perf_counter() + 4.0 * seconds + 120.0
+        while len(res) < len(procs) and time.perf_counter() < deadline:
+            try:
+                res.append(q.get(timeout=2.0))
+            except Exception:
+                if not any(p.is_alive() for p in procs):
+                    break
+        for p in procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.kill()
+        ok = [r for r in res if r and "error" not in r and r["seconds"] > 0]
+        errs = [r["error"] for r in res if r and "error" in r]
+        if not ok:
+            return None, errs
+        return dict(value=sum(r["expansions"] / r["seconds"] for r in ok), sims_per_sec=sum(r["sims"] / r["seconds"] for r in ok),
+                    procs=len(ok), moves=sum(r["moves"] for r in ok), games=sum(r["games"] for r in ok)), errs
+
+    secs = max(3.0, args.cpu_seconds / 2)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            qv, per = f.read().split()
+            if qv != "max":
+                usable = int(min(usable, float(qv) / float(per)))
+    except Exception:
+        pass
+    nproc = args.cpu_procs or max(1, min(usable - 1, 128))
+    kind = "reference"
+    one, errs = run("reference_c", 1, secs)
+    many = None
+    if one is None:
+        kind = "port"
+        one, errs = run("port", 1, secs)
+    elif nproc > 1:
+        many, e2 = run("reference_c", nproc, secs)
+        errs += e2
+    if one is None:
+        return {"value": None, "unit": "node-expansions/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % errs[:1]}
+    out = {"value": (many or one)["value"], "unit": "node-expansions/s", "cores": (many["procs"] if many else 1), "kind": kind,
+           "sample": "per process: fresh games (seed 20260925 + i, + n_procs, ...), %d sims/move, pool %d, moves %d-%d of every game "
+                     "timed, game after game for %.0f s; %s" % (sims, max_nodes, warm + 1, warm + timed, secs,
+                     "the reference's compiled MCTSAgent with evaluator type 1, a Python random playout (agents/VanillaC.py)"
+                     if kind == "reference" else "oracle C restatement of agents/Vanilla.py"),
+           "one_core": one, "all_cores": many}
+    if kind == "reference":
+        port, e3 = run("port", 1, secs)
+        out["oracle_port_one_core"] = port
+    if os.path.isdir(os.environ.get("TETRIS_MCTS_REFERENCE", "/root/reference")):
+        py, e4 = run("reference_py", 1, secs)
+        out["python_agent_one_core"] = py and dict(py, what="agents/Vanilla.py of the reference, imported unmodified (oracle/ref_shims.py)")
+        errs += e4
+    else:
+        out["python_agent_one_core"] = None
+    if errs:
+        out["worker_errors"] = errs[:3]
     return out
 
 

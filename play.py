@@ -106,8 +106,10 @@ def main(argv=None):
         game.play(action)
         agent.update_root(game)
         moves += 1
-        if args.online and not args.benchmark and hasattr(agent, 'train_nodes') and moves % 25 == 0:
-            agent.train_nodes()     # fits the value net on the tuples GC harvested so far (ValueSim.py:161-185)
+        if args.online and not args.benchmark and hasattr(agent, 'train_if_collected'):
+            # the reference trains inside remove_nodes(), i.e. at every collection (ValueSim.py:101-120); the batched engine
+            # harvests on the device during the move and fits here, right after a move in which a collection harvested
+            agent.train_if_collected()
         ended = np.atleast_1d(game.end)
         if ended.any():
             scores, lines = np.atleast_1d(game.score), np.atleast_1d(game.line_clears)

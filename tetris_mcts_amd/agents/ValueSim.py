@@ -66,6 +66,16 @@ class ValueSim(TreeAgent):
         np.savez(path, states=state.cpu().numpy(), values=value.cpu().numpy(), variance=variance.cpu().numpy(),
                  weights=visit.cpu().numpy())
 
+    def train_if_collected(self, **kwargs):
+        """train_nodes() if a garbage collection has harvested tuples since the last call (the reference's remove_nodes ->
+        store_nodes -> train_nodes chain, ValueSim.py:101-120, runs at every collection); None otherwise."""
+        from .. import dist as tdist
+        if not self.online or self.store is None or self.store.s.replay_cap == 0:
+            return None
+        if tdist.all_sum(int(self.store.t["replay_count"].sum().item()), self.store.device) == 0:
+            return None
+        return self.train_nodes(**kwargs)
+
     def train_nodes(self, dump_data=False, dump_path="./data/dump", **train_kwargs):
         import torch
         from .. import dist as tdist

@@ -242,20 +242,23 @@ __device__ __forceinline__ int req_at(const ReqList& rq, int incl, int p, int la
 
 // fc1 (1792 -> 256) + ReLU on v_mfma_f32_16x16x4_f32 (D[16x16] += A[16x4] B[4x16]; lane l: A[i=l&15][k=l>>4],
 // B[k=l>>4][j=l&15], D[i=(l>>4)*4+r][j=l&15]; per output a k-ordered fma chain, 4 terms per instruction).
-// A workgroup of 8 waves owns 32 states x 128 hidden units: every wave a 16-row hidden tile and both 16-state
-// tiles (two independent accumulators), two waves per SIMD so one wave's LDS / L2 waits hide behind the other's
-// MFMAs.  Activations are staged through LDS in FC_KC-wide K chunks, weight quads double-buffered in registers.
+// A workgroup of 8 waves owns 32 states x 64 hidden units (FC_NY = 4 workgroups per 32-state tile): wave w the 16-row
+// hidden tile 4 blockIdx.y + (w & 3) and the 16-state tile w >> 2, two waves per SIMD so one wave's LDS / L2 waits hide
+// behind the other's MFMAs.  Activations are staged through LDS in FC_KC-wide K chunks, weight quads double-buffered in
+// registers.  (r03 gave a tile two workgroups of 128 units: with the dense request list a launch has 60-100 tiles, which left
+// half of the CUs without a workgroup and every workgroup with twice the matrix work: 40 us whatever the number of tiles.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef TM_FC_KC
 #define TM_FC_KC 256   // 7 chunks (half the workgroup barriers of 128): fc1 39.2 -> 36.5 us
 #endif
 constexpr int FC_KC = TM_FC_KC, FC_PITCH = FC_KC + 4;
-// The output layer (256 -> 2, sigmoid, affine) is folded in: a tile's two workgroups (the two halves of the hidden units)
-// store their half of h with write-through (sc1) stores, wait for them, and arrive on the tile's counter; the SECOND to
-// arrive reads the other half with sc1 loads (the valid hand-off form of MI355X_MICROARCH.md: 16-byte sc1 stores and loads,
-// no fences) and runs the 2 x 256 fma chains of its 32 states - the same chain, in the same order, as k_fc_out.  Nobody
-// waits for anybody.  `cnt`: one int per tile (the first pad word of the scratch row of the tile's first state), zero before
-// the first launch (the kernel leaves it zero).
+// The output layer (256 -> 2, sigmoid, affine) is folded in: a tile's FC_NY workgroups (quarters of the hidden units) store
+// their part of h with write-through (sc1) stores, wait for them, and arrive on the tile's counter; the LAST to arrive reads
+// the other parts with sc1 loads (the valid hand-off form of MI355X_MICROARCH.md: 16-byte sc1 stores and loads, no fences)
+// and runs the 2 x 256 fma chains of its 32 states - the same chain, in the same order, as k_fc_out.  Nobody waits for
+// anybody.  `cnt`: one int per tile (the first pad word of the scratch row of the tile's first state), zero before the first
+// launch (the kernel leaves it zero).
+constexpr int FC_NY = 4, FC_UNITS = HID / FC_NY;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
@@ -279,11 +282,13 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
         }
         // (read after the __syncthreads of the K loop)
     }
-    const int ht = blockIdx.y * 8 + w;   // 16-row hidden tile 0..15
+    const int ht = blockIdx.y * (FC_UNITS / 16) + (w & 3);   // 16-row hidden tile 0..15
+    const int stt = w >> 2;                                   // 16-state tile of the 32
+    static_assert(FC_UNITS == 64, "eight waves = four hidden tiles x two state tiles");
     const float4* W = reinterpret_cast<const float4*>(prep + PREP_W1) + (size_t)ht * 112 * 64 + lane;
-    f32x4 acc0, acc1;
+    f32x4 acc0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc0[r] = acc1[r] = P[OFF_F1B + 16 * ht + kk * 4 + r];
+    for (int r = 0; r < 4; ++r) acc0[r] = P[OFF_F1B + 16 * ht + kk * 4 + r];
     // staging: 32 rows x FC_KC floats per chunk, FC_KC/4 threads per row, 16-byte pieces
     constexpr int TPR = FC_KC / 4, RPP = 512 / TPR, NPASS = 32 / RPP;
     const int row0 = threadIdx.x / TPR, c4 = (threadIdx.x % TPR) * 4;
@@ -315,8 +320,7 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
 #pragma unroll 2
     for (int c = 0; c < NCH; ++c) {
         if (c + 1 < NCH) { gload(c + 1); wload(c + 1, (c + 1) & 1); }
-        const float* b0 = &bt[c & 1][l15 * FC_PITCH + kk];
-        const float* b1 = &bt[c & 1][(16 + l15) * FC_PITCH + kk];
+        const float* b0 = &bt[c & 1][(16 * stt + l15) * FC_PITCH + kk];
 #pragma unroll
         for (int q = 0; q < QPC; ++q) {
             const float4 w4 = wbuf[c & 1][q];
@@ -325,7 +329,6 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
                 const float a = (r == 0) ? w4.x : (r == 1) ? w4.y : (r == 2) ? w4.z : w4.w;
                 const int ks = 4 * (4 * q + r);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0[ks], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[ks], acc1, 0, 0, 0);
             }
         }
         if (c + 1 < NCH) lstore((c + 1) & 1);
@@ -338,19 +341,15 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     constexpr int HS_PITCH = HID + 4;
     static_assert(32 * HS_PITCH <= 2 * 32 * FC_PITCH, "hidden tile fits the staging buffers");
     {
-        f32x4v o0, o1;
+        f32x4v o0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { o0[r] = acc0[r] > 0.f ? acc0[r] : 0.f; o1[r] = acc1[r] > 0.f ? acc1[r] : 0.f; }
-        if (s0 + l15 < n) {
-            float* dst = hout + (size_t)(s0 + l15) * hstride + i0;
+        for (int r = 0; r < 4; ++r) o0[r] = acc0[r] > 0.f ? acc0[r] : 0.f;
+        const int row = 16 * stt + l15;
+        if (s0 + row < n) {
+            float* dst = hout + (size_t)(s0 + row) * hstride + i0;
             asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(o0) : "memory");
         }
-        if (s0 + 16 + l15 < n) {
-            float* dst = hout + (size_t)(s0 + 16 + l15) * hstride + i0;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(o1) : "memory");
-        }
-        *reinterpret_cast<f32x4v*>(&hs[l15 * HS_PITCH + i0]) = o0;
-        *reinterpret_cast<f32x4v*>(&hs[(16 + l15) * HS_PITCH + i0]) = o1;
+        *reinterpret_cast<f32x4v*>(&hs[row * HS_PITCH + i0]) = o0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __shared__ int last_flag;
@@ -358,22 +357,28 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     if (threadIdx.x == 0) {
         const int old = __hip_atomic_fetch_add(&cnt[(size_t)blockIdx.x * cnt_stride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = old;
-        if (old == 1) __hip_atomic_store(&cnt[(size_t)blockIdx.x * cnt_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        if (old == FC_NY - 1) __hip_atomic_store(&cnt[(size_t)blockIdx.x * cnt_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
     }
     __syncthreads();
-    if (last_flag != 1) return;
-    // ---- this workgroup arrived second: the other half of h past the caches (32 states x 128 units = 1024 x 16 bytes) ----
+    if (last_flag != FC_NY - 1) return;
+    // ---- this workgroup arrived last: the other parts of h past the caches (32 states x 192 units = 1536 x 16 bytes) ----
     {
-        const int ob = (1 - (int)blockIdx.y) * 128;
+        // three 16-byte loads per thread in flight together, one wait
+        const int e = threadIdx.x, row = e >> 4, c4 = (e & 15) * 4;
+        f32x4v wv[FC_NY - 1];
+        const bool in = s0 + row < n;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int e = it * 512 + threadIdx.x, row = e >> 5, c4 = (e & 31) * 4;
-            if (s0 + row < n) {
-                const float* src = hout + (size_t)(s0 + row) * hstride + ob + c4;
-                f32x4v w;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(src) : "memory");
-                *reinterpret_cast<f32x4v*>(&hs[row * HS_PITCH + ob + c4]) = w;
-            }
+        for (int it = 0; it < FC_NY - 1; ++it) {
+            const int part = it + (it >= (int)blockIdx.y ? 1 : 0);      // the quarters that are not this workgroup's
+            const float* src = hout + (size_t)(s0 + (in ? row : 0)) * hstride + part * FC_UNITS + c4;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(wv[it]) : "v"(src) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]) :: "memory");
+        static_assert(FC_NY == 4, "three other parts");
+#pragma unroll
+        for (int it = 0; it < FC_NY - 1; ++it) {
+            const int part = it + (it >= (int)blockIdx.y ? 1 : 0);
+            if (in) *reinterpret_cast<f32x4v*>(&hs[row * HS_PITCH + part * FC_UNITS + c4]) = wv[it];
         }
     }
     __syncthreads();
@@ -449,7 +454,7 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     if (blocks > 256 * TM_CONV_WG_PER_CU) blocks = 256 * TM_CONV_WG_PER_CU;   // resident workgroups, waves stride over the states
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, rq,
                        max_nodes, n, scratch, SS);
-    hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, 2), dim3(512), 0, stream, P, prepared, scratch, SS, n,
+    hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, FC_NY), dim3(512), 0, stream, P, prepared, scratch, SS, n,
                        scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
     return (int)hipGetLastError();
 }
