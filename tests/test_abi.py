@@ -120,7 +120,7 @@ def test_the_product_never_touches_the_oracle():
         top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
         assert not any((getattr(n, "module", None) or "").startswith("oracle") for n in top), path
         return users
-    assert oracle_users(os.path.join(ROOT, "bench.py")) <= {"_cpu_worker", "cpu_baseline"}
+    assert oracle_users(os.path.join(ROOT, "bench.py")) <= {"_cpu_worker", "_cpu_worker_vanilla", "cpu_baseline", "cpu_baseline_vanilla"}
     assert oracle_users(os.path.join(ROOT, "__graft_entry__.py")) <= {"smoke"}
 
 
