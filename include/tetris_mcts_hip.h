@@ -174,6 +174,10 @@ typedef struct tm_store {
     float *obs_eval;      /* [G][N][4] */
     int32_t eval_parity;  /* 0 / 1, see eval_list */
     int32_t eval_epoch;
+    /* TM_KIND_DIST with online != 0: the distributions of the harvested nodes (DistValueSimOnline.store_nodes,
+       agents/DistValueSimOnline.py:116-141: a freed node with >= min_visits_to_store visits whose seven children have all been
+       visited; replay_obs = its packed observation, replay_stat = (0, 0, visits, 0)) */
+    float *replay_dist;   /* [G][replay_cap][TM_DIST_ROW] */
 } tm_store;
 #define TM_EVAL_SEGS(n_games) ((n_games) < 64 ? (n_games) : 64)
 

@@ -49,7 +49,7 @@ def lib():
         L.orc_agent_expand_game.argtypes = [vp, vp]
         L.orc_agent_remove_nodes.argtypes = [vp]
         for name in ("child", "score", "n_to_o", "visit", "value", "variance", "end_obs", "obs_state", "games",
-                     "stats", "mem_state", "mem_value", "mem_variance", "mem_visit", "rng"):
+                     "stats", "mem_state", "mem_value", "mem_variance", "mem_visit", "mem_dist", "rng"):
             f = getattr(L, "orc_agent_" + name)
             f.restype, f.argtypes = vp, [vp]
         for name in ("root", "episode", "error", "n_avail", "n_obs_avail", "memory_index"):
@@ -261,6 +261,14 @@ class Agent:
                     np.zeros(0, np.float32))
         return (self._arr("mem_state", np.int8, (m, 200)).copy(), self._arr("mem_value", np.float32, (m,)).copy(),
                 self._arr("mem_variance", np.float32, (m,)).copy(), self._arr("mem_visit", np.float32, (m,)).copy())
+
+    def memory_dist(self):
+        """kind 6, online: (states int8 [m,200], distributions [m,bins], visits [m]) stored by the collections so far"""
+        m = self.L.orc_agent_memory_index(self.h)
+        if m == 0:
+            return np.zeros((0, 200), np.int8), np.zeros((0, self.bins), np.float32), np.zeros(0, np.float32)
+        return (self._arr("mem_state", np.int8, (m, 200)).copy(), self._arr("mem_dist", np.float32, (m, self.bins)).copy(),
+                self._arr("mem_visit", np.float32, (m,)).copy())
 
     def __getattr__(self, name):
         if name in ("root", "episode", "error", "n_avail", "n_obs_avail", "memory_index", "n_sims", "n_expand",

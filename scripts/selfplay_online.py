@@ -1,6 +1,9 @@
 """Online self-play learning curve: batched ValueSimLP with GC-harvested TD targets and periodic fits of the value net
-(the reference's `python play.py --agent_type ValueSimLP --online ...`, README.md:36, scaled to many games at once).
-Writes one JSON line per training round: episodes finished since the last round and their mean lines / score."""
+(the reference's `python play.py --agent_type ValueSimLP --online ...`, README.md:36, scaled to many games at once), or
+`--agent DistValueSim`: the distributional head fitted on the distributions of the nodes the collections free
+(DistValueSimOnline.py:116-170).  Writes one JSON line per training round: the episodes finished since the last round with
+their mean lines / score, and - without survivorship bias - the lines cleared per 1000 moves by ALL games in the round and the
+mean over every episode that was under way in it (finished ones with their final count, the others with their count so far)."""
 import argparse
 import json
 import os
@@ -22,6 +25,7 @@ ap.add_argument("--max-nodes", type=int, default=30000)
 ap.add_argument("--minutes", type=float, default=8.0)
 ap.add_argument("--train-every", type=int, default=100, help="moves between training attempts")
 ap.add_argument("--train-iters", type=int, default=3000)
+ap.add_argument("--min-visits", type=int, default=None, help="min_visits_to_store (default: the agent's)")
 ap.add_argument("--out", default="gpurun_out/online_learning.jsonl")
 args = ap.parse_args()
 
@@ -30,14 +34,21 @@ os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
 G = args.games
 env_args = ((20, 10), 1, 0, 0)
 game = Tetris(*env_args, seed=1234, n_games=G)
-model = M.Model_VV(backend="hip", seed=0)
+extra = {} if args.min_visits is None else dict(min_visits_to_store=args.min_visits)
+if args.agent.startswith("Dist"):
+    from tetris_mcts_amd.model_distributional import Model_Dist
+    model = Model_Dist(atoms=50, seed=0, backend="hip")
+else:
+    model = M.Model_VV(backend="hip", seed=0)
 agent = getattr(agents, args.agent)(sims=args.sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=args.max_nodes,
-                                    model=model, online=True, replay_cap=16384)
+                                    model=model, online=True, replay_cap=16384, **extra)
 agent.update_root(game)
 t0 = t_round = time.time()
 moves, rounds = 0, 0
 ep_lines, ep_scores, ep_len = [], [], []
 alive = np.zeros(G, np.int64)
+lines_round, moves_round = 0, 0          # lines cleared / moves played by all games since the last round
+prev_lines = np.zeros(G, np.int64)
 log = open(args.out, "w")
 while time.time() - t0 < args.minutes * 60:
     act = agent.play()
@@ -45,12 +56,17 @@ while time.time() - t0 < args.minutes * 60:
     agent.update_root(game)
     moves += 1
     alive += 1
+    cur = np.asarray(game.line_clears, np.int64)
+    lines_round += int((cur - prev_lines).sum())
+    moves_round += G
+    prev_lines = cur.copy()
     ended = game.end
     if ended.any():
         ep_lines += list(game.line_clears[ended])
         ep_scores += list(game.score[ended])
         ep_len += list(alive[ended])
         alive[ended] = 0
+        prev_lines[ended] = 0
         game.reset("ended")
         agent.update_root(game)
     if moves % args.train_every == 0:
@@ -63,6 +79,8 @@ while time.time() - t0 < args.minutes * 60:
                    max_lines=int(np.max(ep_lines)) if ep_lines else None,
                    mean_score=float(np.mean(ep_scores)) if ep_scores else None,
                    mean_episode_moves=float(np.mean(ep_len)) if ep_len else None,
+                   lines_per_1000_moves=1000.0 * lines_round / max(moves_round, 1),
+                   mean_lines_all_episodes_under_way=float(np.mean(list(ep_lines) + list(prev_lines))),
                    new_tuples=tuples, trained=res is not None, train_iters=(res or {}).get("iters"),
                    best_val=(res or {}).get("best_validation"), train_s=round(time.time() - tt, 1),
                    gcs=agent.store.counter("N_GC"), gc_slices=agent.store.counter("GC_SLICES"),
@@ -75,4 +93,5 @@ while time.time() - t0 < args.minutes * 60:
         log.flush()
         print(rec, flush=True)
         ep_lines, ep_scores, ep_len = [], [], []
+        lines_round, moves_round = 0, 0
 log.close()

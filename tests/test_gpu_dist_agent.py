@@ -284,3 +284,92 @@ def test_dist_agent_with_the_distributional_net():
     assert torch.allclose(d.sum(1), torch.ones(G, device=s.device), atol=1e-4)
     mean, var = agent.get_value()
     assert np.isfinite(mean).all() and (np.asarray(var) >= -1e-6).all()
+
+
+@pytest.mark.parametrize("max_nodes,sims,moves", [(3000, 150, 60), (1500, 60, 120)])
+def test_dist_online_harvest_matches_the_oracle(oracle, max_nodes, sims, moves):
+    """The online leg (DistValueSimOnline.store_nodes, agents/DistValueSimOnline.py:116-141): what the collections harvest on the
+    device - freed nodes with enough visits whose seven children were all visited: board, 50-atom distribution, visit count, per
+    game in index order, collection after collection - is what oracle kind 6 stores, bit for bit; the search itself too."""
+    import torch
+    from tetris_mcts_amd import agents, dist as tdist
+    from tetris_mcts_amd.pyTetris import Tetris
+    G = 6
+    env_args = ((20, 10), 1, 0, 0)
+    seeds = 31337 + np.arange(G)
+    game = Tetris(*env_args, seed=seeds, n_games=G)
+    agent = agents.DistValueSim(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=max_nodes, evaluator=hash_dist,
+                                online=True, min_visits_to_store=8, replay_cap=8192)
+    agent.update_root(game)
+    og = [oracle.Game(seed=int(s)) for s in seeds]
+    oa = [oracle.Agent(6, max_nodes=max_nodes, low=5, online=True, min_visits_to_store=8, memory_size=100000) for _ in range(G)]
+    for g in range(G):
+        oa[g].update_root(og[g])
+    for m in range(moves):
+        act = np.atleast_1d(agent.play())
+        stats = agent.get_stats().reshape(G, 3, 7)
+        for g in range(G):
+            a = oa[g].play(sims)
+            assert oa[g].error == 0
+            assert a == act[g] and oa[g].stats().tobytes() == stats[g].tobytes(), (m, g)
+            og[g].play(a)
+            oa[g].update_root(og[g])
+        game.play(act)
+        agent.update_root(game)
+        ended = np.atleast_1d(game.end)
+        if ended.any():
+            game.reset("ended")
+            agent.update_root(game)
+            for g in np.nonzero(ended)[0]:
+                og[g].reset()
+                oa[g].update_root(og[g])
+    s = agent.store
+    assert (s.errors() == 0).all() and s.counter("N_DROPPED") == 0
+    cnt = s.t["replay_count"].cpu().numpy()
+    total = 0
+    for g in range(G):
+        st, d, v = oa[g].memory_dist()
+        assert cnt[g] == len(v), (g, cnt[g], len(v))
+        if cnt[g] == 0:
+            continue
+        keys = s.t["replay_obs"][g, :cnt[g]]
+        dev_states = tdist.render_observations(keys).reshape(-1, 200).cpu().numpy().astype(np.int8)
+        assert np.array_equal(dev_states, st), g
+        assert s.t["replay_dist"][g, :cnt[g], :50].cpu().numpy().tobytes() == d.tobytes(), g
+        assert s.t["replay_stat"][g, :cnt[g], 2].cpu().numpy().tobytes() == v.tobytes(), g
+        total += int(cnt[g])
+    assert total > 50 and s.counter("N_GC") == sum(o.n_gc for o in oa) > G
+    # the agent's drain: the same tuples, the buffers emptied
+    keys, dists, visits = agent.harvested()
+    assert keys.shape[0] == total and int(s.t["replay_count"].sum().item()) == 0
+
+
+def test_dist_online_training_round():
+    """harvest -> train_nodes: the head is fitted on the harvested distributions (Model_Dist.loss through train.train_data), the
+    HIP operand streams are rebuilt, and the search goes on with the new weights."""
+    import torch
+    from tetris_mcts_amd import agents
+    from tetris_mcts_amd.model_distributional import Model_Dist
+    from tetris_mcts_amd.pyTetris import Tetris
+    G, sims = 32, 120
+    env_args = ((20, 10), 1, 0, 0)
+    game = Tetris(*env_args, seed=5, n_games=G)
+    model = Model_Dist(atoms=50, seed=0, backend="hip")
+    agent = agents.DistValueSim(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=2500, model=model, online=True,
+                                min_visits_to_store=8, memory_growth_rate=100)
+    agent.update_root(game)
+    res, before = None, model.flat_params().clone()
+    for m in range(60):
+        act = agent.play()
+        game.play(act)
+        agent.update_root(game)
+        if game.end.any():
+            game.reset("ended")
+            agent.update_root(game)
+        out = agent.train_if_collected(max_iters=60, iters_per_val=20, batch_size=256)
+        if agent.n_trains >= 2:
+            break
+    assert agent.n_trains >= 2 and (agent.store.errors() == 0).all()
+    assert not torch.equal(before, model.flat_params())
+    d = model.inference_device(torch.zeros(4, 200, dtype=torch.int8, device="cuda"))[:, :50]
+    assert torch.isfinite(d).all() and torch.allclose(d.sum(1), torch.ones(4, device="cuda"), atol=1e-5)

@@ -150,3 +150,25 @@ def test_checkpoint_round_trips_with_a_reference_layout_optimizer_state(tmp_path
     mdl2.model = M.Net()
     mdl2.load(path)
     assert mdl2.optimizer is not None
+
+
+def test_distributional_head_fit_and_loss():
+    """Model_Dist.loss = KL(target || softmax) with 0 log 0 = 0 (the reference's expression, model_distributional.py:84-98, is NaN
+    at empty target atoms), weighted per sample; train_data (the generic train loop with this loss) lowers it."""
+    import torch
+    from tetris_mcts_amd.model_distributional import Model_Dist
+    torch.manual_seed(3)
+    m = Model_Dist(atoms=50, device="cpu", seed=1, backend="torch")
+    n = 300
+    x = torch.zeros(n, 1, 22, 10)
+    x[:, 0, 12:, :] = (torch.rand(n, 10, 10) < 0.5).float()
+    t = torch.zeros(n, 50)
+    t[torch.arange(n), (x.sum((1, 2, 3)) / 4).long().clamp(max=49)] = 0.75      # a target with empty atoms
+    t[torch.arange(n), ((x.sum((1, 2, 3)) / 4).long() + 1).clamp(max=49)] += 0.25
+    w = torch.rand(n, 1) + 0.5
+    mean, std = m.loss(x, t, w)
+    ref = (w * (torch.where(t > 0, t * t.clamp(min=1e-30).log(), torch.zeros_like(t)) - t * m.model.log_prob(x))).sum(1)
+    assert torch.isfinite(mean) and torch.allclose(mean, ref.mean(), rtol=1e-6)
+    before = float(m.loss(x, t)[0])
+    m.train_data([x, t, w], batch_size=64, iters_per_val=50, max_iters=150, log=False)
+    assert float(m.loss(x, t)[0]) < 0.8 * before

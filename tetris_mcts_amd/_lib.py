@@ -25,6 +25,7 @@ class TmStore(C.Structure):
         ("node_dist", vp), ("eval_dist", vp), ("nq_table_d", vp), ("dist_vmin", f64), ("dist_vmax", f64), ("dist_bins", i32),
         ("gc_spec_nodes", i32),
         ("eval_list", vp), ("eval_cnt", vp), ("obs_eval", vp), ("eval_parity", i32), ("eval_epoch", i32),
+        ("replay_dist", vp),
     ]
 
 

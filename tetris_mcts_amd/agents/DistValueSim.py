@@ -24,16 +24,21 @@ class DistValueSim(TreeAgent):
     kind = st.KIND_DIST
     low = 5
 
-    def __init__(self, atoms=50, vmin=0, vmax=5000, max_nodes=100000, model=None, evaluator=None, online=False, **kwargs):
+    def __init__(self, atoms=50, vmin=0, vmax=5000, max_nodes=100000, model=None, evaluator=None, online=False,
+                 min_visits_to_store=50, memory_size=500000, memory_growth_rate=5000, **kwargs):
+        """online: the reference's online leg (DistValueSimOnline.py:116-170) - a collection stores the freed nodes with at
+        least `min_visits_to_store` visits whose seven children have all been visited (its commented store_nodes, default 50)
+        as (board, distribution, visits) tuples, train_nodes fits the head on them (memory_size / memory_growth_rate as
+        ValueSim's)."""
         kwargs.pop("min_visit", None)
         kwargs.pop("gamma", None)                      # the distributional backup does not discount
         self.atoms, self.vrange = int(atoms), (float(vmin), float(vmax))
         self.evaluator = evaluator
-        if online:
-            from sys import stderr
-            print("DistValueSim: online training of the distributional head is not built (the reference's own train_nodes "
-                  "reads a memory its store_nodes - commented out - never fills); running with online=False", file=stderr)
-        super().__init__(max_nodes=max_nodes, online=False, **kwargs)
+        benchmark = kwargs.get("benchmark", False)
+        self.online = bool(online) and not benchmark
+        kwargs.setdefault("replay_cap", min(int(max_nodes), 16384) if self.online else 0)
+        self.memory_size, self.memory_growth_rate, self.n_trains, self._memory = int(memory_size), int(memory_growth_rate), 0, None
+        super().__init__(max_nodes=max_nodes, online=self.online, min_visits_to_store=min_visits_to_store, **kwargs)
         if evaluator is None:
             from ..model_distributional import Model_Dist
             self.model = model if model is not None else Model_Dist(atoms=self.atoms)
@@ -80,3 +85,60 @@ class DistValueSim(TreeAgent):
         var = (d * centre * centre).sum(1) - mean * mean
         mean, var = mean.cpu().numpy(), var.cpu().numpy()
         return (mean[0], var[0]) if self.n_games == 1 else (mean, var)
+
+    # ---- online training (DistValueSimOnline.py:143-170): tuples harvested on the device at the collections (tree.hip dist_keep /
+    # dist_harvest_store), all-gathered over the ranks, the head fitted on their union with Model_Dist's loss ----
+    def train_if_collected(self, **kwargs):
+        from .. import dist as tdist
+        if not self.online or self.store is None or self.store.s.replay_cap == 0:
+            return None
+        if tdist.all_sum(int(self.store.t["replay_count"].sum().item()), self.store.device) == 0:
+            return None
+        return self.train_nodes(**kwargs)
+
+    def harvested(self):
+        """(packed observations int32 [n,12], distributions float32 [n,64], visits float32 [n]) of this rank since the last
+        drain; the device buffers are emptied."""
+        s = self.store
+        keys, dists, visits = s.replay_dist()
+        keys, dists, visits = keys.clone(), dists.clone(), visits.clone()
+        s.t["replay_count"].zero_()
+        return keys, dists, visits
+
+    def train_nodes(self, dump_data=False, dump_path="./data/memory_dump", **train_kwargs):
+        from sys import stderr
+        from .. import dist as tdist
+        if not self.online or self.evaluator is not None:
+            return None
+        keys, dists, visits = self.harvested()
+        dropped = self.store.counter("N_DROPPED")
+        if dropped > getattr(self, "_dropped_seen", 0):
+            print("WARNING: {} harvested tuples did not fit the device replay buffer (replay_cap={})".format(
+                dropped - getattr(self, "_dropped_seen", 0), self.store.s.replay_cap), file=stderr, flush=True)
+            self._dropped_seen = dropped
+        if self._memory is not None:
+            keys, dists, visits = (torch.cat([a, b]) for a, b in zip(self._memory, (keys, dists, visits)))
+        keys, dists, visits = keys[:self.memory_size], dists[:self.memory_size], visits[:self.memory_size]
+        keys_all, dists_all, visits_all = tdist.all_gather_rows(keys.view(torch.int32), dists, visits)
+        d_size = int(keys_all.shape[0])
+        m_size = min(self.n_trains * self.memory_growth_rate, self.memory_size)
+        if d_size < max(m_size, 1):
+            print("Not enough training data ({} < {}), collecting more data.".format(d_size, m_size), file=stderr, flush=True)
+            self._memory = (keys, dists, visits)
+            return None
+        print("Enough training data ({} >= {}), proceed to training.".format(d_size, m_size), file=stderr, flush=True)
+        states = torch.zeros(d_size, 1, 22, 10, dtype=torch.float32, device=keys_all.device)
+        states[:, :, 2:, :] = tdist.render_observations(keys_all)          # the net's 22 rows: two empty ones on top
+        data = [states, dists_all[:, :self.atoms].contiguous(), visits_all.reshape(-1, 1)]
+        if dump_data and tdist.rank() == 0:
+            import os
+            os.makedirs(os.path.dirname(os.path.abspath(dump_path)), exist_ok=True)
+            np.savez(dump_path, states=data[0].cpu().numpy(), values=data[1].cpu().numpy(), weights=data[2].cpu().numpy())
+        self.n_trains += 1
+        opts = dict(iters_per_val=100, batch_size=1024, max_iters=50000)     # DistValueSimOnline.py:165
+        opts.update(train_kwargs)
+        res = self.model.train_data(data, **opts)
+        self.model.training(False)
+        self._memory = None
+        print("Training complete.", file=stderr, flush=True)
+        return res

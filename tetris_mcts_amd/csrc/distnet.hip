@@ -300,19 +300,21 @@ __global__ __launch_bounds__(512) void k_dn_fc(const float* __restrict__ P, cons
     // staging: 16 rows x FC_KC floats per chunk, 64 threads per row, 16-byte pieces, two passes of 8 rows
     constexpr int TPR = FC_KC / 4, RPP = 512 / TPR, NPASS = FC_ST / RPP;
     const int row0 = threadIdx.x / TPR, c4 = (threadIdx.x % TPR) * 4;
-    float4 st[NPASS];
+    // the activations of chunk c + 2 are requested while chunk c is multiplied (two register sets): the rows come from beyond
+    // this XCD's L2 (written by convolution waves all over the chip), a round trip one chunk of MFMAs does not cover
+    float4 st[2][NPASS];
     auto gload = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const int sa = s0 + row0 + RPP * i;
-            st[i] = (sa < n) ? *reinterpret_cast<const float4*>(a2 + (size_t)sa * a2stride + chunk * FC_KC + c4)
-                             : make_float4(0, 0, 0, 0);
+            st[chunk & 1][i] = (sa < n) ? *reinterpret_cast<const float4*>(a2 + (size_t)sa * a2stride + chunk * FC_KC + c4)
+                                        : make_float4(0, 0, 0, 0);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i)
-            *reinterpret_cast<float4*>(&bt[buf][(row0 + RPP * i) * FC_PITCH + c4]) = st[i];
+            *reinterpret_cast<float4*>(&bt[chunk & 1][(row0 + RPP * i) * FC_PITCH + c4]) = st[chunk & 1][i];
     };
     constexpr int NCH = KFC / FC_KC, QPC = FC_KC / 16;
     float4 wbuf[2][QPC];
@@ -321,12 +323,13 @@ __global__ __launch_bounds__(512) void k_dn_fc(const float* __restrict__ P, cons
         for (int q = 0; q < QPC; ++q) wbuf[buf][q] = W[((size_t)chunk * QPC + q) * 64];
     };
     gload(0);
+    gload(1);
     wload(0, 0);
     lstore(0);
     __syncthreads();
 #pragma unroll 2
     for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) { gload(c + 1); wload(c + 1, (c + 1) & 1); }
+        if (c + 1 < NCH) wload(c + 1, (c + 1) & 1);
         const float* b0 = &bt[c & 1][l15 * FC_PITCH + kk];
 #pragma unroll
         for (int q = 0; q < QPC; ++q) {
@@ -337,7 +340,8 @@ __global__ __launch_bounds__(512) void k_dn_fc(const float* __restrict__ P, cons
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0[4 * (4 * q + r)], acc, 0, 0, 0);
             }
         }
-        if (c + 1 < NCH) lstore((c + 1) & 1);
+        if (c + 1 < NCH) lstore(c + 1);
+        if (c + 2 < NCH) gload(c + 2);
         __syncthreads();
     }
     // hidden layer of the 16 states -> LDS hs[state][unit] (the staging buffers are free now)

@@ -82,6 +82,7 @@ int tm_store_slice(const tm_store* s, int first, int n, tm_store* out) {
     t.eval_list += f * (size_t)s->eval_slots * 2;
     t.eval_cnt += f * 2;
     if (t.obs_eval) t.obs_eval += f * N * 4;
+    if (t.replay_dist) t.replay_dist += f * (size_t)s->replay_cap * TM_DIST_ROW;
     *out = t;
     return 0;
 }

@@ -1494,6 +1494,67 @@ template <int T> struct Grp {
 
 // One group of T threads, the whole collection, now (update_root's exhausting pop, the single-call entry points,
 // tm_tree_remove_nodes).  sm: Grp<T>::NW + 1 ints of LDS (unused for T == 64).
+// The online leg of the distributional agent: DistValueSimOnline.store_nodes (agents/DistValueSimOnline.py:116-141 - commented
+// out in the reference, rebuilt as SURVEY 8(f)2 asks): a node that a collection frees becomes a training tuple when it has at
+// least min_visits visits and every one of its seven children has been visited (a missing child is node 0, whose visit count
+// is 0); the tuple = (its board, its distribution, its visit count).  The decision reads the children's statistics, which the
+// same collection may be clearing: it is taken where nothing is cleared yet (the count step / a pass of its own) and left in
+// bit 26 of the node's record header; the write step copies the nodes that carry it, in index order.
+constexpr uint32_t HDR_HARVEST = 1u << 26;
+__device__ __forceinline__ bool dist_keep(const tm_store& S, const GP& P, int idx) {
+    const float v = __uint_as_float(P.stat()[(size_t)idx * 4]);
+    if (!(v >= (float)S.min_visits_to_store)) return false;
+    const uint4* kd = reinterpret_cast<const uint4*>(P.kids() + (size_t)idx * TM_KIDS_DW);
+    const uint4 k0 = kd[0], k1 = kd[1];
+    const uint32_t c[7] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z};
+    float cv[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) cv[a] = __uint_as_float(P.stat()[(size_t)c[a] * 4]);
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 7; ++a) ok = ok && c[a] != 0u && cv[a] >= 1.0f;
+    return ok;
+}
+// marks the freed nodes of bitmap word wi that are training tuples; returns how many
+__device__ __forceinline__ int dist_mark_word(const tm_store& S, const GP& P, uint32_t freed, int wi, int low_node) {
+    int n = 0;
+    if (wi * 32 + 31 < low_node) return 0;
+    for (uint32_t bits = freed; bits; bits &= bits - 1) {
+        const int i = wi * 32 + (__ffs(bits) - 1);
+        if (i < low_node || i == 0) continue;
+        if (dist_keep(S, P, i)) {
+            uint32_t* h = P.rec() + (size_t)i * TM_REC_DW + TM_REC_HDR;
+            *h = *h | HDR_HARVEST;
+            n += 1;
+        }
+    }
+    return n;
+}
+__device__ __forceinline__ uint32_t dist_marked(const GP& P, uint32_t freed, int wi, int low_node) {
+    uint32_t keep = 0;
+    if (wi * 32 + 31 < low_node) return 0u;
+    for (uint32_t bits = freed; bits; bits &= bits - 1) {
+        const int b = __ffs(bits) - 1, i = wi * 32 + b;
+        if (i >= low_node && (P.rec()[(size_t)i * TM_REC_DW + TM_REC_HDR] & HDR_HARVEST)) keep |= 1u << b;
+    }
+    return keep;
+}
+__device__ __forceinline__ void dist_harvest_store(const tm_store& S, const GP& P, int g, int idx, int kpos) {
+    uint32_t gm[GAME_DW], ok[OBS_DW];
+    const uint4* src = reinterpret_cast<const uint4*>(P.game() + (size_t)idx * GAME_DW);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const uint4 q = src[t]; gm[4 * t] = q.x; gm[4 * t + 1] = q.y; gm[4 * t + 2] = q.z; gm[4 * t + 3] = q.w; }
+    pack_obs(gm, ok);
+    uint4* dk = reinterpret_cast<uint4*>(S.replay_obs + ((size_t)g * S.replay_cap + kpos) * TM_OBS_DW);
+    dk[0] = make_uint4(ok[0], ok[1], ok[2], ok[3]); dk[1] = make_uint4(ok[4], ok[5], ok[6], ok[7]); dk[2] = make_uint4(ok[8], ok[9], ok[10], ok[11]);
+    float* ds = S.replay_stat + ((size_t)g * S.replay_cap + kpos) * 4;
+    ds[0] = 0.f; ds[1] = 0.f; ds[2] = __uint_as_float(P.stat()[(size_t)idx * 4]); ds[3] = 0.f;      // weight = the visit count
+    const uint4* sd = reinterpret_cast<const uint4*>(S.node_dist + ((size_t)g * P.n() + (size_t)idx) * TM_DIST_ROW);
+    uint4* dd = reinterpret_cast<uint4*>(S.replay_dist + ((size_t)g * S.replay_cap + kpos) * TM_DIST_ROW);
+#pragma unroll
+    for (int t = 0; t < TM_DIST_ROW / 4; ++t) dd[t] = sd[t];
+}
+
 template <int T>
 __device__ __forceinline__ void gc_collect(const tm_store& S, const GP& P, int g, int tid, int* sm) {
     typedef Grp<T> G_;
@@ -1590,14 +1651,34 @@ __device__ __forceinline__ void gc_collect(const tm_store& S, const GP& P, int g
     {
         const int n_words = (N + 31) / 32;
         const int low_obs = gs[TM_GS_LOW_OBS], low_node = gs[TM_GS_LOW_NODE];
-        const bool harvest = S.online && S.replay_cap > 0;
-        int m = harvest ? S.replay_count[g] : 0;
+        const bool dharvest = S.online && S.replay_cap > 0 && S.kind == TM_KIND_DIST && S.replay_dist;
+        const bool harvest = S.online && S.replay_cap > 0 && S.kind != TM_KIND_DIST;
+        int m = (harvest || dharvest) ? S.replay_count[g] : 0;
+        if (dharvest) {      // the tuples are chosen before anything is cleared (dist_keep reads the children's statistics)
+            for (int wi = tid; wi < n_words; wi += T) {
+                const int rem = N - wi * 32;
+                dist_mark_word(S, P, ~nmw[wi] & (rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u)), wi, low_node);
+            }
+            G_::sync();
+        }
         for (int wbase = 0; wbase < n_words; wbase += T) {
             const int wi = wbase + tid;
             uint32_t valid = 0;
             if (wi < n_words) { const int rem = N - wi * 32; valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u); }
             // ---- nodes ----
             const uint32_t fr = (wi < n_words) ? (~nmw[wi] & valid) : 0u;
+            if (dharvest) {
+                const uint32_t keepmask = dist_marked(P, fr, wi, low_node);
+                int ktotal;
+                int kpos = m + G_::exscan(__popc(keepmask), tid, sm, ktotal);
+                for (uint32_t bits = keepmask; bits; bits &= bits - 1) {
+                    if (kpos < S.replay_cap) dist_harvest_store(S, P, g, wi * 32 + (__ffs(bits) - 1), kpos);
+                    kpos += 1;
+                }
+                if (tid == 0 && m + ktotal > S.replay_cap) gs[TM_GS_N_DROPPED] += m + ktotal - S.replay_cap;
+                m = min(S.replay_cap, m + ktotal);
+                G_::sync();      // the copies have read what the loops below clear
+            }
             int total;
             int pos = nfree + G_::exscan(__popc(fr), tid, sm, total);
             for (uint32_t bits = fr; bits; bits &= bits - 1) {
@@ -1671,6 +1752,7 @@ __device__ __forceinline__ void gc_collect(const tm_store& S, const GP& P, int g
             onfree += ototal;
             if (harvest) { G_::sync(); if (tid == 0) S.replay_count[g] = m; }
         }
+        if (dharvest && tid == 0) S.replay_count[g] = m;
         G_::sync();
     }
     {
@@ -1881,7 +1963,8 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
     const size_t bm_bytes = (((size_t)N + 7) / 8 + 15) & ~(size_t)15;
     const uint32_t mask = (uint32_t)S.table_cap - 1u;
     const int n_words = (N + 31) / 32;
-    const bool harvest = S.online && S.replay_cap > 0;
+    const bool dharvest = S.online && S.replay_cap > 0 && S.kind == TM_KIND_DIST && S.replay_dist;
+    const bool harvest = S.online && S.replay_cap > 0 && S.kind != TM_KIND_DIST;
     // THE LAUNCH'S PLAN (every workgroup derives the same one: the control words it reads were written in earlier launches,
     // or are written in this one only after every workgroup has arrived for the game).
     // The bounded steps first, as many as fit the launch's cost allowance - those of the waiting games oldest request first,
@@ -1996,7 +2079,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
             for (int b = 0; b < n_b; ++b) { nf += part[3 * b]; of += part[3 * b + 1]; kf += part[3 * b + 2]; }
             gs[TM_GS_NFREE_NODE] = nf;
             gs[TM_GS_NFREE_OBS] = of;
-            if (harvest) {
+            if (harvest || dharvest) {
                 const int m0 = S.replay_count[g];
                 if (m0 + kf > S.replay_cap) gs[TM_GS_N_DROPPED] += m0 + kf - S.replay_cap;   // never silently (the reference keeps all up to memory_size)
                 S.replay_count[g] = min(S.replay_cap, m0 + kf);
@@ -2150,6 +2233,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                 const int rem = N - wi * 32;
                 const uint32_t valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u);
                 nf += __popc(~nmw[wi] & valid);
+                if (dharvest) kf += dist_mark_word(S, P, ~nmw[wi] & valid, wi, gs[TM_GS_LOW_NODE]);     // (nothing is cleared in this step)
                 const uint32_t ofr = ~omw[wi] & valid;
                 of += __popc(ofr);
                 if (harvest && wi * 32 + 31 >= low_obs) {
@@ -2171,13 +2255,24 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
             // the statistics are cleared (16 B): a visit count of 0 keeps a slot that stays free from being harvested again.
             const int lo = (int)((long long)n_words * p0 / n_parts), hi = (int)((long long)n_words * p1 / n_parts);
             const int low_obs = gs[TM_GS_LOW_OBS], low_node = gs[TM_GS_LOW_NODE];
-            int nbase = 0, obase = 0, kbase = harvest ? S.replay_count[g] : 0;      // (the count is updated by the step's last workgroup)
+            int nbase = 0, obase = 0, kbase = (harvest || dharvest) ? S.replay_count[g] : 0;      // (the count is updated by the step's last workgroup)
             for (int b = 0; b < my_part; ++b) { nbase += part[3 * b]; obase += part[3 * b + 1]; kbase += part[3 * b + 2]; }
             for (int wbase = lo; wbase < hi; wbase += T) {
                 const int wi = wbase + tid;
                 uint32_t valid = 0;
                 if (wi < hi) { const int rem = N - wi * 32; valid = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u); }
                 const uint32_t fr = (wi < hi) ? (~nmw[wi] & valid) : 0u;
+                if (dharvest) {
+                    // the tuples the count step chose (header bit 26), copied before this thread clears the slots
+                    const uint32_t keepmask = dist_marked(P, fr, wi, low_node);
+                    int ktotal;
+                    int kpos = kbase + G_::exscan(__popc(keepmask), tid, sm, ktotal);
+                    kbase += ktotal;
+                    for (uint32_t bits = keepmask; bits; bits &= bits - 1) {
+                        if (kpos < S.replay_cap) dist_harvest_store(S, P, g, wi * 32 + (__ffs(bits) - 1), kpos);
+                        kpos += 1;
+                    }
+                }
                 int total;
                 int pos = nbase + G_::exscan(__popc(fr), tid, sm, total);
                 for (uint32_t bits = fr; bits; bits &= bits - 1) {

@@ -269,18 +269,20 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     __shared__ int row_slot[32];          // request mode: where row j of the tile delivers its outputs
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, l15 = lane & 15;
     const int s0 = blockIdx.x * 32;
+    int my_slot = 0;
     if (rq.list) {
         // rows = dense positions of the request list; a tile past its end has nothing to do (both of its workgroups leave)
         const int incl = req_prefix(rq, lane, n);
         if (s0 >= n) return;
         if (w == 0) {
-            for (int j = 0; j < 32; ++j) {
-                const int p = s0 + j < n ? s0 + j : n - 1;
-                const int at = req_at(rq, incl, p, lane);
-                if (lane == 0) row_slot[j] = rq.list[at].x;
-            }
+            // lane j < 32 resolves row j (all 32 list entries in flight together; the slot is needed after the K loop only)
+            const int p = min(s0 + (lane & 31), n - 1);
+            int sg = 0;
+            for (int k = 0; k < rq.segs; ++k) sg += __builtin_amdgcn_readlane(incl, k) <= p ? 1 : 0;     // first segment whose inclusive prefix exceeds p
+            const int before = __shfl(incl, sg > 0 ? sg - 1 : 0, 64);
+            const int d = p - (sg > 0 ? before : 0);
+            my_slot = rq.list[(sg + rq.segs * (d / rq.slots)) * rq.slots + d % rq.slots].x;
         }
-        // (read after the __syncthreads of the K loop)
     }
     const int ht = blockIdx.y * (FC_UNITS / 16) + (w & 3);   // 16-row hidden tile 0..15
     const int stt = w >> 2;                                   // 16-state tile of the 32
@@ -292,19 +294,22 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     // staging: 32 rows x FC_KC floats per chunk, FC_KC/4 threads per row, 16-byte pieces
     constexpr int TPR = FC_KC / 4, RPP = 512 / TPR, NPASS = 32 / RPP;
     const int row0 = threadIdx.x / TPR, c4 = (threadIdx.x % TPR) * 4;
-    float4 st[NPASS];
+    // The activations of chunk c + 2 are requested while chunk c is multiplied (two register sets): a tile's rows were written
+    // by convolution waves all over the chip, so they come from beyond this XCD's L2, and one chunk of MFMAs (under 2 us) does
+    // not cover that round trip.
+    float4 st[2][NPASS];
     auto gload = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             int sa = s0 + row0 + RPP * i;
-            st[i] = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4)
-                             : make_float4(0, 0, 0, 0);
+            st[chunk & 1][i] = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4)
+                                        : make_float4(0, 0, 0, 0);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i)
-            *reinterpret_cast<float4*>(&bt[buf][(row0 + RPP * i) * FC_PITCH + c4]) = st[i];
+            *reinterpret_cast<float4*>(&bt[chunk & 1][(row0 + RPP * i) * FC_PITCH + c4]) = st[chunk & 1][i];
     };
     constexpr int NCH = A3 / FC_KC;   // chunks of FC_KC k = FC_KC/4 MFMA steps = FC_KC/16 weight quads
     constexpr int QPC = FC_KC / 16;
@@ -314,12 +319,14 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
         for (int q = 0; q < QPC; ++q) wbuf[buf][q] = W[((size_t)chunk * QPC + q) * 64];
     };
     gload(0);
+    gload(1);
     wload(0, 0);
     lstore(0);
     __syncthreads();
+    static_assert(NCH >= 2, "two chunks in flight");
 #pragma unroll 2
     for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) { gload(c + 1); wload(c + 1, (c + 1) & 1); }
+        if (c + 1 < NCH) wload(c + 1, (c + 1) & 1);
         const float* b0 = &bt[c & 1][(16 * stt + l15) * FC_PITCH + kk];
 #pragma unroll
         for (int q = 0; q < QPC; ++q) {
@@ -331,7 +338,8 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0[ks], acc0, 0, 0, 0);
             }
         }
-        if (c + 1 < NCH) lstore((c + 1) & 1);
+        if (c + 1 < NCH) lstore(c + 1);          // (requested a whole chunk ago)
+        if (c + 2 < NCH) gload(c + 2);           // into the register set chunk c's staging has just left
         __syncthreads();
     }
     // D[i = kk*4 + r][j = l15]: four consecutive hidden units of one state per lane -> one 16-byte write-through store,
@@ -351,6 +359,7 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
         }
         *reinterpret_cast<f32x4v*>(&hs[row * HS_PITCH + i0]) = o0;
     }
+    if (rq.list && w == 0 && lane < 32) row_slot[lane] = my_slot;      // (the list entry has had the whole K loop to arrive)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __shared__ int last_flag;
     __syncthreads();
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
         const int j = threadIdx.x >> 1, o = threadIdx.x & 1;
         int sidx = s0 + j;
         const bool live = sidx < n;
-        if (rq.list) sidx = row_slot[j];
+        if (rq.list) sidx = row_slot[j];          // (written by wave 0 before the barrier above)
         if (live) {
             float acc = P[OFF_FOB + o];
             const float* x = &hs[j * HS_PITCH];

@@ -67,6 +67,37 @@ def all_gather_tuples(obs_keys, stats, group=None):
     return allp[:, :12].contiguous(), allp[:, 12:].contiguous().view(torch.float32)
 
 
+def all_gather_rows(*cols, group=None):
+    """All-gather variable-length rows made of several 4-byte-element tensors with the same first dimension (the
+    distributional agent's tuples: packed observation int32 [n,12], distribution float32 [n,64], visits float32 [n]): one count
+    all-gather + one padded payload all-gather of the bit-cast columns; returns the columns concatenated over ranks in rank
+    order, with their dtypes and trailing shapes."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return cols
+    world = dist.get_world_size(group)
+    dev = cols[0].device
+    n_loc = cols[0].shape[0]
+    flat = [c.reshape(n_loc, -1).contiguous().view(torch.int32) for c in cols]
+    widths = [f.shape[1] for f in flat]
+    n = torch.tensor([n_loc], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    if m == 0:
+        return cols
+    pay = torch.zeros(m, sum(widths), dtype=torch.int32, device=dev)
+    pay[:n_loc] = torch.cat(flat, dim=1)
+    out = [torch.empty_like(pay) for _ in range(world)]
+    dist.all_gather(out, pay, group=group)
+    allp = torch.cat([out[r][:counts[r]] for r in range(world)], dim=0)
+    res, off = [], 0
+    for c, w in zip(cols, widths):
+        res.append(allp[:, off:off + w].contiguous().view(c.dtype).reshape((allp.shape[0],) + tuple(c.shape[1:])))
+        off += w
+    return tuple(res)
+
+
 def render_observations(obs_keys):
     """Packed observations int32 [n,12] -> float32 [n,1,20,10] network inputs (0 empty, 1 locked, -1 falling piece);
     the layout of the reference's replay memory (ValueSim.py:24-29).  Plain tensor ops (off the hot path)."""

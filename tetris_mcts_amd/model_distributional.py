@@ -138,9 +138,40 @@ class Model_Dist:
         return [self.model(b).cpu().numpy()]     # something in the two hidden rows: only the torch ops take 22 rows
 
     def loss(self, state, value, weight=None):
+        """model_distributional.py:84-98: -value * (log p - log value) summed over the atoms = KL(value || p), optionally
+        weighted.  The reference's expression is NaN wherever a target atom is exactly 0 (0 * -inf; its targets would be the
+        search's shifted distributions, whose lowest bins are empty): value * log value is taken as 0 there (torch.xlogy), the
+        same number everywhere else."""
         lp = self.model.log_prob(state)
-        per = -value * (lp - value.log())
+        per = torch.xlogy(value, value) - value * lp
         if weight is not None:
-            per = weight.squeeze() * per          # model_distributional.py:93-94
+            per = weight.reshape(-1, 1) * per     # model_distributional.py:93-94 (weight.squeeze() broadcasts over the LAST axis
+                                                  # there, which only lines up for batch == atoms; per-sample weights are what is meant)
         std, mean = torch.std_mean(per.sum(dim=1))
         return mean, std
+
+    def _optimizer(self):
+        if getattr(self, "optimizer", None) is None:
+            # Model_Dist.__init__ (model_distributional.py:66): what the class ends up with (its _init_model's Yogi is overwritten)
+            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=1e-4, eps=1e-5, amsgrad=True)
+        return self.optimizer
+
+    def train_data(self, data, **kwargs):
+        """data: [states [n,1,22,10], distributions [n,atoms], weights [n,1]]; Model.train_data (model/model.py:176-249) with
+        this class's loss; data-parallel over the ranks as train.train_data describes."""
+        from . import train as T
+        data = [torch.as_tensor(d, dtype=torch.float32, device=self.device) for d in data]
+        best = {}
+
+        def save():
+            best["model"] = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+
+        def load():
+            self.model.load_state_dict(best["model"])
+
+        def loss_fn(net, batch, weighted):
+            return self.loss(batch[0], batch[1], batch[2] if weighted else None)
+        res = T.train_data(self.model, self._optimizer(), data, save=save, load=load, loss_fn=loss_fn, **kwargs)
+        self.model.eval()
+        self.weights_changed()
+        return res

@@ -92,6 +92,8 @@ class TreeStore:
         self.t["eval_list"] = z(G * eval_slots, 2)
         self.t["eval_cnt"] = z(G, 2)
         self.t["obs_eval"] = z(G, N, 4, dtype=torch.float32) if kind in (KIND_VALUESIM, KIND_CPPAGENT) else None
+        # the distributional agent's harvest (DistValueSimOnline.store_nodes): the freed nodes' distributions
+        self.t["replay_dist"] = z(G, replay_cap, 64, dtype=torch.float32) if (kind == KIND_DIST and online and replay_cap > 0) else None
         self.t["nq_table"] = norm_quantile_table(nq_size, dev)
         # TM_KIND_DIST only: the nodes' value distributions, the evaluator's output, norm_quantile in double
         is_dist = kind == KIND_DIST
@@ -250,3 +252,10 @@ class TreeStore:
         cnt = self.t["replay_count"].clamp(max=self.s.replay_cap)
         idx = torch.arange(self.t["replay_obs"].shape[1], device=self.device)[None, :] < cnt[:, None]
         return self.t["replay_obs"][idx], self.t["replay_stat"][idx]
+
+    def replay_dist(self):
+        """TM_KIND_DIST: (packed observations, distributions [n, 64], visit counts) of the nodes harvested by GC
+        (DistValueSimOnline.store_nodes, agents/DistValueSimOnline.py:116-141), per game in index order."""
+        cnt = self.t["replay_count"].clamp(max=self.s.replay_cap)
+        idx = torch.arange(self.t["replay_obs"].shape[1], device=self.device)[None, :] < cnt[:, None]
+        return self.t["replay_obs"][idx], self.t["replay_dist"][idx], self.t["replay_stat"][idx][:, 2]

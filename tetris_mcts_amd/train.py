@@ -77,13 +77,14 @@ def batch_loss(net, batch, weighted, variance_clip=variance_bound):
 
 
 @torch.no_grad()
-def validation_loss(net, data, weighted, chunk=1024):
+def validation_loss(net, data, weighted, chunk=1024, loss_fn=None):
     """Weighted combination over chunks (model.py:49-84): chunk weight = sum of sample weights (or the count)."""
     tot_w, acc, acc2 = 0.0, 0.0, 0.0
+    loss_fn = loss_fn or batch_loss
     for c in range(0, data[0].shape[0], chunk):
         b = [d[c:c + chunk] for d in data]
-        mean, std = batch_loss(net, b, weighted)
-        w = float(b[3].sum()) if weighted else float(b[0].shape[0])
+        mean, std = loss_fn(net, b, weighted)
+        w = float(b[-1].sum()) if weighted else float(b[0].shape[0])
         mean, std = float(mean), float(std)
         if math.isnan(std):
             std = 0.0
@@ -105,8 +106,10 @@ def check_data_parallel_batch(batch_size, world):
 def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validation_fraction=0.1,
                sample_replacement=True, oversampling=False, weighted=True, early_stopping=True, early_stopping_patience=10,
                early_stopping_threshold=1.0, shuffle=False, max_iters=100000, grad_clip=0.0, save=None, load=None,
-               generator=None, log=True, data_parallel=True, group=None):
-    """data = [states f32 [n,1,20,10], values [n,1], variances [n,1], weights [n,1]] (device tensors).
+               generator=None, log=True, data_parallel=True, group=None, loss_fn=None):
+    """data = [states f32 [n,1,20,10], values [n,1], variances [n,1], weights [n,1]] (device tensors); with `loss_fn`
+    (net, batch, weighted) -> (mean, std) any list of arrays whose LAST one holds the sample weights (Model.train_data is
+    generic in the reference too, model/model.py:176-249: the model class supplies `_loss`).
     save() / load() persist and restore the best weights (the reference goes through its checkpoint file).
 
     With torch.distributed initialised and more than one rank (every rank holding the same data and the same weights, as
@@ -126,7 +129,8 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
     n = data[0].shape[0]
     n_val = int(n * validation_fraction)
     data = list(data)
-    data[3] = data[3] / data[3].mean()
+    data[-1] = data[-1] / data[-1].mean()
+    loss_fn = loss_fn or batch_loss
     if shuffle:
         perm = torch.randperm(n, device=data[0].device, generator=generator)
         data = [d[perm] for d in data]
@@ -141,7 +145,7 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
     net.train()
     for it in range(max_iters):
         if oversampling:    # model.py:194-195: draw proportionally to the visit weights
-            idx = torch.multinomial(train[3].reshape(-1), batch_size, replacement=sample_replacement, generator=generator)
+            idx = torch.multinomial(train[-1].reshape(-1), batch_size, replacement=sample_replacement, generator=generator)
         elif sample_replacement:
             idx = torch.randint(0, n - n_val, (batch_size,), device=data[0].device, generator=generator)
         else:
@@ -149,7 +153,7 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
         if world > 1:
             idx = idx[my_rank::world]
         optimizer.zero_grad(set_to_none=True)
-        loss, _ = batch_loss(net, [d[idx] for d in train], weighted)
+        loss, _ = loss_fn(net, [d[idx] for d in train], weighted)
         loss.backward()
         if world > 1:
             grads = [p.grad for p in net.parameters() if p.grad is not None]
@@ -169,7 +173,7 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
         iters_done = it + 1
         if (it + 1) % iters_per_val == 0 and val is not None:
             net.eval()
-            vmean, vstd = validation_loss(net, val, weighted)
+            vmean, vstd = validation_loss(net, val, weighted, loss_fn=loss_fn)
             net.train()
             vstd /= max(n_val, 1) ** 0.5
             mark = ""
