@@ -278,7 +278,13 @@ int tm_core_get_unique_child_obs(int n_trees, int n_nodes, const int32_t *index,
 int tm_core_get_all_childs(int n_trees, int n_nodes, const int32_t *roots, const int32_t *child,
                            uint8_t *mark /* [B][n_nodes] */, int32_t *queue /* [B][n_nodes] scratch */, void *stream);
 
-/* distributional head helpers (agents/cppmodule/core.h:387-449; defined there, not exported by core.cpp): n categorical
+/* The array-level distribution helpers below (tm_dist_*, tm_distpy_*) and tm_core_get_all_childs are the compatibility
+ * surface of the reference's function-per-call API: ONE LANE PER TREE / DISTRIBUTION (scalar code per lane, as the reference's
+ * loops are written), meant for callers that keep the reference's arrays.  The engine's own search does this work at wave
+ * level inside tm_sim_step (tree.hip: wave_dist_front / wave_dist_back, one lane per atom; the collectors' breadth-first
+ * marking) and does not call them.
+ *
+ * distributional head helpers (agents/cppmodule/core.h:387-449; defined there, not exported by core.cpp): n categorical
  * distributions of `bins` atoms over [vmin, vmax).  tm_dist_transform: every source bin is an interval `scale` bins wide
  * shifted by shift[i] (in value units), its mass split over the two destination bins it overlaps (mass beyond the last
  * bin is dropped - the reference writes one float past its vector there).  tm_dist_mean_variance: out[i] = (mean, variance)

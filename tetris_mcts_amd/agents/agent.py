@@ -111,6 +111,8 @@ class TreeAgent(Agent):
                     s.sim_step(both)
                     e[2].record()
                     self._pending_events.append(e)
+                    if len(self._pending_events) >= 256:
+                        self._fold_events()                 # bounded whether or not anybody reads loop_stats()
                 else:
                     self.evaluate_requests()
                     s.sim_step(both)
@@ -123,15 +125,24 @@ class TreeAgent(Agent):
                     s.gc_step()
                 todo, collecting = s.sims_remaining()
 
+    def _fold_events(self, wait=False):
+        """completed event triples into the running sums (all of them after a synchronize)"""
+        import torch
+        if wait:
+            torch.cuda.synchronize()
+        keep = []
+        for e in self._pending_events:
+            if wait or e[2].query():
+                self.loop_events["nn_ms_sum"] += e[0].elapsed_time(e[1])
+                self.loop_events["tree_ms_sum"] += e[1].elapsed_time(e[2])
+                self.loop_events["timed"] += 1
+            else:
+                keep.append(e)
+        self._pending_events = keep
+
     def loop_stats(self, reset=True):
         """Python-driven loop only: dict(timed, nn_ms_sum, tree_ms_sum, catchup_launches) from the sampled event triples"""
-        import torch
-        torch.cuda.synchronize()
-        for e in self._pending_events:
-            self.loop_events["nn_ms_sum"] += e[0].elapsed_time(e[1])
-            self.loop_events["tree_ms_sum"] += e[1].elapsed_time(e[2])
-            self.loop_events["timed"] += 1
-        self._pending_events = []
+        self._fold_events(wait=True)
         out = dict(self.loop_events, catchup_launches=self.catchup_launches)
         if reset:
             self.loop_events = dict(timed=0, nn_ms_sum=0.0, tree_ms_sum=0.0)

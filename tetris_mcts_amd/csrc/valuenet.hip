@@ -328,15 +328,33 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     for (int c = 0; c < NCH; ++c) {
         if (c + 1 < NCH) wload(c + 1, (c + 1) & 1);
         const float* b0 = &bt[c & 1][(16 * stt + l15) * FC_PITCH + kk];
+        // The B operands (LDS) of the next 16 MFMA steps are requested while this group's 16 MFMAs issue (r03 - r04 call C:
+        // the compiler's own order was read, wait for it, two MFMAs, read ...: an LDS round trip per pair of MFMAs, 45 us per
+        // launch whatever the number of tiles, against 12 us of matrix-core time).
+        constexpr int GRP = 16, NGRP = FC_KC / 4 / GRP;
+        float bb[2][GRP];
+        auto load_b = [&](int grp, int buf) {
 #pragma unroll
-        for (int q = 0; q < QPC; ++q) {
-            const float4 w4 = wbuf[c & 1][q];
+            for (int i = 0; i < GRP; ++i) bb[buf][i] = b0[4 * (GRP * grp + i)];
+        };
+        load_b(0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+        for (int gq = 0; gq < NGRP; ++gq) {
+            if (gq + 1 < NGRP) load_b(gq + 1, (gq + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                const float4 w4 = wbuf[c & 1][(GRP * gq + i) / 4];
+                const int r = i & 3;
                 const float a = (r == 0) ? w4.x : (r == 1) ? w4.y : (r == 2) ? w4.z : w4.w;
-                const int ks = 4 * (4 * q + r);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0[ks], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[gq & 1][i], acc0, 0, 0, 0);
             }
+            // issue order inside the group: an LDS read behind every other MFMA (the reads pair up into ds_read2_b32)
+#pragma unroll
+            for (int i = 0; i < GRP / 2; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // the next group's reads stay in this group's region: a whole group ahead of their use
         }
         if (c + 1 < NCH) lstore(c + 1);          // (requested a whole chunk ago)
         if (c + 2 < NCH) gload(c + 2);           // into the register set chunk c's staging has just left

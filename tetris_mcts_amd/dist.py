@@ -18,12 +18,15 @@ def shard_range(n_total, rank, world):
     return start, base + (1 if rank < rem else 0)
 
 
-def game_seeds(base_seed, games_per_rank, rank, world=None):
+def game_seeds(base_seed, games_per_rank, rank, world=None, start=None):
     """Environment seeds of one rank's games: game g of rank r is game r * games_per_rank + g of the job, seeded
     base_seed + that index - a game's whole trajectory depends on its index in the job only, never on how many ranks
-    the job has or on which of them it runs (tests/test_dist.py)."""
+    the job has or on which of them it runs (tests/test_dist.py).  `games_per_rank` is the shard size of EVERY rank (equal
+    shards, what bench.py and the agents use); with the uneven shards of shard_range() pass the shard's `start` (its first
+    game's index in the job) instead, so that adjacent ranks do not overlap."""
     import numpy as np
-    return int(base_seed) + int(rank) * int(games_per_rank) + np.arange(int(games_per_rank), dtype=np.int64)
+    first = int(rank) * int(games_per_rank) if start is None else int(start)
+    return int(base_seed) + first + np.arange(int(games_per_rank), dtype=np.int64)
 
 
 def rank(group=None):
