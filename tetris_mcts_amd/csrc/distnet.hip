@@ -317,22 +317,25 @@ __global__ __launch_bounds__(512) void k_dn_fc(const float* __restrict__ P, cons
             *reinterpret_cast<float4*>(&bt[chunk & 1][(row0 + RPP * i) * FC_PITCH + c4]) = st[chunk & 1][i];
     };
     constexpr int NCH = KFC / FC_KC, QPC = FC_KC / 16;
-    float4 wbuf[2][QPC];
-    auto wload = [&](int chunk, int buf) {
+    // weights: a ring of three groups of four quads (16 MFMA steps each), the group two ahead requested while a group is
+    // multiplied - 48 registers instead of the 128 of a double-buffered chunk, so that two workgroups share a CU
+    constexpr int GRP = 16, NGRP = FC_KC / 4 / GRP, WRING = 3;
+    static_assert(QPC == 4 * NGRP, "a group = four weight quads");
+    float4 wring[WRING][4];
+    auto wload = [&](int G) {          // G = chunk * NGRP + group
 #pragma unroll
-        for (int q = 0; q < QPC; ++q) wbuf[buf][q] = W[((size_t)chunk * QPC + q) * 64];
+        for (int q = 0; q < 4; ++q) wring[G % WRING][q] = W[((size_t)G * 4 + q) * 64];
     };
     gload(0);
     gload(1);
-    wload(0, 0);
+    wload(0);
+    wload(1);
     lstore(0);
     __syncthreads();
-#pragma unroll 2
+#pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) wload(c + 1, (c + 1) & 1);
         const float* b0 = &bt[c & 1][l15 * FC_PITCH + kk];
         // the B operands (LDS) of the next 16 MFMA steps are requested while this group's 16 MFMAs issue (valuenet.hip k_vn_fc1)
-        constexpr int GRP = 16, NGRP = FC_KC / 4 / GRP;
         float bb[2][GRP];
         auto load_b = [&](int grp, int buf) {
 #pragma unroll
@@ -341,10 +344,12 @@ __global__ __launch_bounds__(512) void k_dn_fc(const float* __restrict__ P, cons
         load_b(0, 0);
 #pragma unroll
         for (int gq = 0; gq < NGRP; ++gq) {
+            const int G = c * NGRP + gq;
+            if (G + 2 < NCH * NGRP) wload(G + 2);
             if (gq + 1 < NGRP) load_b(gq + 1, (gq + 1) & 1);
 #pragma unroll
             for (int i = 0; i < GRP; ++i) {
-                const float4 w4 = wbuf[c & 1][(GRP * gq + i) / 4];
+                const float4 w4 = wring[G % WRING][i / 4];
                 const int r = i & 3;
                 const float a = (r == 0) ? w4.x : (r == 1) ? w4.y : (r == 2) ? w4.z : w4.w;
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[gq & 1][i], acc, 0, 0, 0);
