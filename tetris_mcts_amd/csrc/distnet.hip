@@ -317,9 +317,9 @@ __global__ __launch_bounds__(512) void k_dn_fc(const float* __restrict__ P, cons
             *reinterpret_cast<float4*>(&bt[chunk & 1][(row0 + RPP * i) * FC_PITCH + c4]) = st[chunk & 1][i];
     };
     constexpr int NCH = KFC / FC_KC, QPC = FC_KC / 16;
-    // weights: a ring of three groups of four quads (16 MFMA steps each), the group two ahead requested while a group is
-    // multiplied - 48 registers instead of the 128 of a double-buffered chunk, so that two workgroups share a CU
-    constexpr int GRP = 16, NGRP = FC_KC / 4 / GRP, WRING = 3;
+    // weights: a ring of WRING groups of four quads (16 MFMA steps each), the group WRING - 1 ahead requested while a group is
+    // multiplied (one workgroup per CU: the lead of five groups covers the L2 round trip, valuenet.hip k_vn_fc1)
+    constexpr int GRP = 16, NGRP = FC_KC / 4 / GRP, WRING = 6;
     static_assert(QPC == 4 * NGRP, "a group = four weight quads");
     float4 wring[WRING][4];
     auto wload = [&](int G) {          // G = chunk * NGRP + group
@@ -328,8 +328,8 @@ __global__ __launch_bounds__(512) void k_dn_fc(const float* __restrict__ P, cons
     };
     gload(0);
     gload(1);
-    wload(0);
-    wload(1);
+#pragma unroll
+    for (int G0 = 0; G0 < WRING - 1; ++G0) wload(G0);
     lstore(0);
     __syncthreads();
 #pragma unroll
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(512) void k_dn_fc(const float* __restrict__ P, cons
 #pragma unroll
         for (int gq = 0; gq < NGRP; ++gq) {
             const int G = c * NGRP + gq;
-            if (G + 2 < NCH * NGRP) wload(G + 2);
+            if (G + WRING - 1 < NCH * NGRP) wload(G + WRING - 1);
             if (gq + 1 < NGRP) load_b(gq + 1, (gq + 1) & 1);
 #pragma unroll
             for (int i = 0; i < GRP; ++i) {

@@ -260,6 +260,10 @@ constexpr int FC_KC = TM_FC_KC, FC_PITCH = FC_KC + 4;
 // launch (the kernel leaves it zero).
 constexpr int FC_NY = 4, FC_UNITS = HID / FC_NY;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+// WRING: groups of 16 MFMA steps whose weights are in registers (see the K loop): 6 = a lead of five groups, 166 registers, one
+// workgroup per CU - the launches of the single-leaf kinds (60-100 tiles, at most one workgroup per CU anyway); 3 = 102
+// registers, two workgroups per CU - the leaf-parallel kinds' launches (hundreds of tiles).  Same arithmetic, same bits.
+template <int WRING>
 __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
                                                 float* __restrict__ hout, int hstride,
@@ -269,21 +273,7 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     __shared__ int row_slot[32];          // request mode: where row j of the tile delivers its outputs
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, l15 = lane & 15;
     const int s0 = blockIdx.x * 32;
-    int my_slot = 0;
-    if (rq.list) {
-        // rows = dense positions of the request list; a tile past its end has nothing to do (both of its workgroups leave)
-        const int incl = req_prefix(rq, lane, n);
-        if (s0 >= n) return;
-        if (w == 0) {
-            // lane j < 32 resolves row j (all 32 list entries in flight together; the slot is needed after the K loop only)
-            const int p = min(s0 + (lane & 31), n - 1);
-            int sg = 0;
-            for (int k = 0; k < rq.segs; ++k) sg += __builtin_amdgcn_readlane(incl, k) <= p ? 1 : 0;     // first segment whose inclusive prefix exceeds p
-            const int before = __shfl(incl, sg > 0 ? sg - 1 : 0, 64);
-            const int d = p - (sg > 0 ? before : 0);
-            my_slot = rq.list[(sg + rq.segs * (d / rq.slots)) * rq.slots + d % rq.slots].x;
-        }
-    }
+    const int ncap = n;      // rows of the scratch (request mode: n becomes the number of requests below)
     const int ht = blockIdx.y * (FC_UNITS / 16) + (w & 3);   // 16-row hidden tile 0..15
     const int stt = w >> 2;                                   // 16-state tile of the 32
     static_assert(FC_UNITS == 64, "eight waves = four hidden tiles x two state tiles");
@@ -301,9 +291,10 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     auto gload = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            int sa = s0 + row0 + RPP * i;
-            st[chunk & 1][i] = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4)
-                                        : make_float4(0, 0, 0, 0);
+            // (a row past the end reads the last row: such a row's outputs are never delivered, and the loads need not wait
+            // for the request count)
+            const int sa = min(s0 + row0 + RPP * i, ncap - 1);
+            st[chunk & 1][i] = *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4);
         }
     };
     auto lstore = [&](int chunk) {
@@ -313,9 +304,11 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     };
     constexpr int NCH = A3 / FC_KC;   // chunks of FC_KC k = FC_KC/4 MFMA steps = FC_KC/16 weight quads
     constexpr int QPC = FC_KC / 16;
-    // weights: a ring of three groups of four quads (16 MFMA steps each), the group two ahead requested while a group is
-    // multiplied - 48 registers instead of the 128 of a double-buffered chunk, so that two workgroups share a CU
-    constexpr int GRP = 16, NGRP = FC_KC / 4 / GRP, WRING = 3;
+    // weights: a ring of WRING groups of four quads (16 MFMA steps each), the group WRING - 1 ahead requested while a group is
+    // multiplied (measured, r04 calls C-E per launch of ~60 tiles: chunk-deep weights without the LDS pipeline 45 us, with it
+    // 35 us at 178 registers and one workgroup per CU; a ring of three groups 45 us again - the weights need the longer lead
+    // when nothing else is resident to cover it)
+    constexpr int GRP = 16, NGRP = FC_KC / 4 / GRP;
     static_assert(QPC == 4 * NGRP, "a group = four weight quads");
     float4 wring[WRING][4];
     auto wload = [&](int G) {          // G = chunk * NGRP + group
@@ -324,8 +317,24 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     };
     gload(0);
     gload(1);
-    wload(0);
-    wload(1);
+#pragma unroll
+    for (int G0 = 0; G0 < WRING - 1; ++G0) wload(G0);
+    // (the first activations and weights are on their way while the request list is read)
+    int my_slot = 0;
+    if (rq.list) {
+        // rows = dense positions of the request list; a tile past its end has nothing to do (both of its workgroups leave)
+        const int incl = req_prefix(rq, lane, n);
+        if (s0 >= n) return;
+        if (w == 0) {
+            // lane j < 32 resolves row j (all 32 list entries in flight together; the slot is needed after the K loop only)
+            const int p = min(s0 + (lane & 31), n - 1);
+            int sg = 0;
+            for (int k = 0; k < rq.segs; ++k) sg += __builtin_amdgcn_readlane(incl, k) <= p ? 1 : 0;     // first segment whose inclusive prefix exceeds p
+            const int before = __shfl(incl, sg > 0 ? sg - 1 : 0, 64);
+            const int d = p - (sg > 0 ? before : 0);
+            my_slot = rq.list[(sg + rq.segs * (d / rq.slots)) * rq.slots + d % rq.slots].x;
+        }
+    }
     lstore(0);
     __syncthreads();
     static_assert(NCH >= 2, "two chunks in flight");
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
 #pragma unroll
         for (int gq = 0; gq < NGRP; ++gq) {
             const int G = c * NGRP + gq;
-            if (G + 2 < NCH * NGRP) wload(G + 2);
+            if (G + WRING - 1 < NCH * NGRP) wload(G + WRING - 1);
             if (gq + 1 < NGRP) load_b(gq + 1, (gq + 1) & 1);
 #pragma unroll
             for (int i = 0; i < GRP; ++i) {
@@ -486,8 +495,12 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     if (blocks > 256 * TM_CONV_WG_PER_CU) blocks = 256 * TM_CONV_WG_PER_CU;   // resident workgroups, waves stride over the states
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, rq,
                        max_nodes, n, scratch, SS);
-    hipLaunchKernelGGL(k_vn_fc1, dim3((n + 31) / 32, FC_NY), dim3(512), 0, stream, P, prepared, scratch, SS, n,
-                       scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
+    if (n >= 8192)      // (request slots: the leaf-parallel kinds' seven per game)
+        hipLaunchKernelGGL(k_vn_fc1<3>, dim3((n + 31) / 32, FC_NY), dim3(512), 0, stream, P, prepared, scratch, SS, n,
+                           scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
+    else
+        hipLaunchKernelGGL(k_vn_fc1<6>, dim3((n + 31) / 32, FC_NY), dim3(512), 0, stream, P, prepared, scratch, SS, n,
+                           scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
     return (int)hipGetLastError();
 }
 
