@@ -1,30 +1,30 @@
 #!/bin/bash
-# round 4, GPU call E: FC kernels with a three-group weight ring (two workgroups per CU again)
+# round 4, GPU call G: fc1 ring depth by launch size (no scratch), first loads ahead of the request list
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 cd $R
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/e.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/e.smoke.log | cut -c1-300
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/g.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/g.smoke.log | cut -c1-300
 timeout 900 python -m pytest tests/test_gpu_valuenet.py tests/test_gpu_dist_agent.py tests/test_gpu_tree.py -m gpu -q -x -n 4 \
-   -k "valuenet or hip_head or with_the_hip_head or value_net_in_the_loop" > $OUT/e.new.log 2>&1; echo "new rc=$?"; tail -n 6 $OUT/e.new.log | cut -c1-600
+   -k "valuenet or hip_head or with_the_hip_head or value_net_in_the_loop" > $OUT/g.new.log 2>&1; echo "new rc=$?"; tail -n 6 $OUT/g.new.log | cut -c1-600
 show() { python - <<PY
 import json
 d=json.load(open('$1'))
-print('$1', {k:e.get(k) for k in ('value','ms_per_step')}, d['requests']['fraction_not_posted'])
+print('$1', {k:d.get(k) for k in ('value','ms_per_step')}, d['requests']['fraction_not_posted'])
 for rk in ('roofline','roofline_other'):
     if rk in d: print('  ', d[rk]['kernel'][:40], d[rk]['avg_launch_ms'], d[rk]['frac'])
 if 'steady_state' in d:
     ss=d['steady_state']; print('   steady', ss['value'], ss['ms_per_step'], ss['gc']['catchup_launches_per_move'], ss['tree_kernel_ms'], ss['value_net_ms'], ss.get('episodes_finished'), ss.get('lines_cleared_per_episode'))
-for k,v in e.get('other_configs',{}).items():
+for k,v in d.get('other_configs',{}).items():
     print('  ', k, {kk:v.get(kk) for kk in ('value','ms_per_step','error')}, [(v[rk]['avg_launch_ms'], v[rk]['frac']) for rk in ('roofline','roofline_other') if rk in v])
 PY
 }
-timeout 600 python bench.py --no-cpu-baseline > $OUT/e.bench.json 2> $OUT/e.bench.err; echo "bench rc=$?"; show $OUT/e.bench.json
+timeout 600 python bench.py --no-cpu-baseline > $OUT/g.bench.json 2> $OUT/g.bench.err; echo "bench rc=$?"; show $OUT/g.bench.json
 HEAD="--no-cpu-baseline --steady-steps 0 --others none"
 prof_kt() {   # name, last, bench args...
   local name=$1 last=$2; shift 2
   cd /tmp; rm -rf /tmp/p_$name
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -- python $R/bench.py "$@" > $R/$OUT/e.kt_$name.json 2> $R/$OUT/e.kt_$name.err; echo "$name kernel trace rc=$?"
-  cd $R; python scripts/kernel_stats.py /tmp/p_$name $OUT/e.kernel_stats_$name.csv --last $last; head -n 5 $OUT/e.kernel_stats_$name.csv | cut -c1-60,150-400
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -- python $R/bench.py "$@" > $R/$OUT/g.kt_$name.json 2> $R/$OUT/g.kt_$name.err; echo "$name kernel trace rc=$?"
+  cd $R; python scripts/kernel_stats.py /tmp/p_$name $OUT/g.kernel_stats_$name.csv --last $last; head -n 5 $OUT/g.kernel_stats_$name.csv | cut -c1-60,150-400
 }
 prof_kt head 10000 $HEAD
 prof_kt lp 10000 --agent ValueSimLP $HEAD

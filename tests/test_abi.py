@@ -174,3 +174,32 @@ def test_control_block_words_match_the_header():
         assert name in gs
     L = _lib()
     assert L.TmStore.gc_spec_nodes.offset == L.TmStore.dist_bins.offset + 4
+
+
+def test_hot_kernels_use_no_scratch_memory(tmp_path):
+    """The kernels of the simulation step keep their working set in registers: a private segment (scratch) in one of them is a
+    silent slowdown (r04: a 16-byte copy into a register array sent the array to scratch memory and fc1 from 35 to 53 us while
+    every result stayed right).  Read from the code objects inside the built HIP objects."""
+    import shutil
+    import subprocess
+    import pytest
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("no llvm binutils")
+    hot = ("k_sim_step", "k_vn_conv", "k_vn_fc1", "k_dn_conv", "k_dn_fc", "k_update_root", "k_root_stats")
+    seen = set()
+    for src in ("tree", "valuenet", "distnet"):
+        obj = os.path.join(ROOT, "tetris_mcts_amd", "csrc", "_obj", src + ".o")
+        if not os.path.exists(obj):
+            pytest.skip("HIP objects not built")
+        local = str(tmp_path / (src + ".o"))
+        shutil.copy(obj, local)
+        subprocess.check_call([objdump, "--offloading", local], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cos = [f for f in os.listdir(tmp_path) if f.startswith(src + ".o.") and "amdgcn" in f]
+        assert cos, "no device code object in " + obj
+        notes = subprocess.check_output([readelf, "--notes", str(tmp_path / cos[0])]).decode()
+        for name, scratch, spills in re.findall(r"\.name:\s+(\S+)\s.*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
+            if any(h in name for h in hot):
+                seen.add(next(h for h in hot if h in name))
+                assert int(scratch) == 0 and int(spills) == 0, (name, scratch, spills)
+    assert seen == set(hot), seen

@@ -291,10 +291,12 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     auto gload = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            // (a row past the end reads the last row: such a row's outputs are never delivered, and the loads need not wait
-            // for the request count)
-            const int sa = min(s0 + row0 + RPP * i, ncap - 1);
-            st[chunk & 1][i] = *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4);
+            // (bounded by the rows of the scratch, not by the request count: a row past the requests holds an earlier launch's
+            // finite values and its outputs are never delivered - and the loads need not wait for the count.  Kept as a
+            // select: a plain 16-byte copy into the array sent the whole array to scratch memory.)
+            const int sa = s0 + row0 + RPP * i;
+            st[chunk & 1][i] = (sa < ncap) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4)
+                                           : make_float4(0, 0, 0, 0);
         }
     };
     auto lstore = [&](int chunk) {
