@@ -34,6 +34,18 @@ def test_hip_valuenet(oracle, golden_dir, pk, ok):
     v1, r1 = m.inference_device(big.contiguous())
     v2, r2 = m.inference_device(big[:5].contiguous())
     assert torch.equal(v1[:5], v2) and torch.equal(r1[:5], r2)
+    # the two tilings of the fc1 kernel (32-state tiles below 8192 states, 64-state tiles from there on: valuenet.hip k_vn_fc1)
+    # are the same arithmetic: a large ragged batch against itself in pieces, and its first 64 states against the oracle's bits
+    huge = states.repeat(141, 1)[torch.randperm(64 * 141, device="cuda")][:9001].contiguous()
+    vh, rh = m.inference_device(huge)
+    vh, rh = vh.clone(), rh.clone()
+    for lo in range(0, 9001, 3000):
+        vp, rp = m.inference_device(huge[lo:lo + 3000].contiguous())
+        assert torch.equal(vh[lo:lo + 3000], vp) and torch.equal(rh[lo:lo + 3000], rp), lo
+    s64 = np.ascontiguousarray(huge[:64].cpu().numpy())
+    ov, ovar = np.zeros(64, np.float32), np.zeros(64, np.float32)
+    oracle.lib().orc_valuenet_forward(oracle.ptr(np.ascontiguousarray(z[pk])), oracle.ptr(s64), 64, oracle.ptr(ov), oracle.ptr(ovar))
+    assert vh[:64].cpu().numpy().tobytes() == ov.tobytes() and rh[:64].cpu().numpy().tobytes() == ovar.tobytes()
 
 
 def test_torch_backend_within_tolerance(golden_dir):

@@ -242,94 +242,47 @@ __device__ __forceinline__ int req_at(const ReqList& rq, int incl, int p, int la
 
 // fc1 (1792 -> 256) + ReLU on v_mfma_f32_16x16x4_f32 (D[16x16] += A[16x4] B[4x16]; lane l: A[i=l&15][k=l>>4],
 // B[k=l>>4][j=l&15], D[i=(l>>4)*4+r][j=l&15]; per output a k-ordered fma chain, 4 terms per instruction).
-// A workgroup of 8 waves owns 32 states x 64 hidden units (FC_NY = 4 workgroups per 32-state tile): wave w the 16-row
-// hidden tile 4 blockIdx.y + (w & 3) and the 16-state tile w >> 2, two waves per SIMD so one wave's LDS / L2 waits hide
-// behind the other's MFMAs.  Activations are staged through LDS in FC_KC-wide K chunks, weight quads double-buffered in
-// registers.  (r03 gave a tile two workgroups of 128 units: with the dense request list a launch has 60-100 tiles, which left
-// half of the CUs without a workgroup and every workgroup with twice the matrix work: 40 us whatever the number of tiles.)
+// A workgroup of 8 waves owns a tile of ROWS = 32 NST states x 64 hidden units (FC_NY = 4 workgroups per tile): wave w the
+// 16-row hidden tile 4 blockIdx.y + (w & 3) and the NST 16-state tiles (w >> 2) NST ..., two waves per SIMD so one wave's
+// waits hide behind the other's MFMAs.  Activations are staged through LDS in KC-wide K chunks (requested two chunks ahead),
+// the B operands read from LDS a group of steps ahead, the weights held in a ring of WRING groups.  Two shapes, the same
+// arithmetic and the same bits (every output element is its own k-ordered chain whatever the tiling):
+//   <1, 256, 6>  32-state tiles, 152 registers, one workgroup per CU: the single-leaf kinds, whose dense request list leaves
+//                60-100 tiles a launch - a latency problem (r03 gave a tile two workgroups of 128 units: half of the CUs
+//                without a workgroup, 40 us whatever the number of tiles; r04 calls B-G: 51 -> 35 us);
+//   <2, 128, 3>  64-state tiles, two workgroups per CU: the leaf-parallel kinds' hundreds of tiles - an L2-bandwidth problem
+//                (every tile streams the 1.8 MB of weights: twice the states per tile = half the stream).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifndef TM_FC_KC
-#define TM_FC_KC 256   // 7 chunks (half the workgroup barriers of 128): fc1 39.2 -> 36.5 us
-#endif
-constexpr int FC_KC = TM_FC_KC, FC_PITCH = FC_KC + 4;
 // The output layer (256 -> 2, sigmoid, affine) is folded in: a tile's FC_NY workgroups (quarters of the hidden units) store
 // their part of h with write-through (sc1) stores, wait for them, and arrive on the tile's counter; the LAST to arrive reads
 // the other parts with sc1 loads (the valid hand-off form of MI355X_MICROARCH.md: 16-byte sc1 stores and loads, no fences)
-// and runs the 2 x 256 fma chains of its 32 states - the same chain, in the same order, as k_fc_out.  Nobody waits for
+// and runs the 2 x 256 fma chains of its states - the same chain, in the same order, as k_fc_out.  Nobody waits for
 // anybody.  `cnt`: one int per tile (the first pad word of the scratch row of the tile's first state), zero before the first
 // launch (the kernel leaves it zero).
 constexpr int FC_NY = 4, FC_UNITS = HID / FC_NY;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-// WRING: groups of 16 MFMA steps whose weights are in registers (see the K loop): 6 = a lead of five groups, 166 registers, one
-// workgroup per CU - the launches of the single-leaf kinds (60-100 tiles, at most one workgroup per CU anyway); 3 = 102
-// registers, two workgroups per CU - the leaf-parallel kinds' launches (hundreds of tiles).  Same arithmetic, same bits.
-template <int WRING>
+template <int NST, int KC, int WRING>
 __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
                                                 float* __restrict__ hout, int hstride,
                                                 ReqList rq, int32_t* __restrict__ cnt, int cnt_stride,
                                                 float* __restrict__ v_out, float* __restrict__ var_out) {
-    __shared__ float bt[2][32 * FC_PITCH];
-    __shared__ int row_slot[32];          // request mode: where row j of the tile delivers its outputs
+    constexpr int ROWS = 32 * NST, PITCH = KC + 4, HS_PITCH = HID + 4;
+    constexpr int BT = ROWS * PITCH > (ROWS * HS_PITCH + 1) / 2 ? ROWS * PITCH : (ROWS * HS_PITCH + 1) / 2;     // floats per staging buffer
+    __shared__ __attribute__((aligned(16))) float bt[2][BT];
+    __shared__ int row_slot[ROWS];        // request mode: where row j of the tile delivers its outputs
+    __shared__ int last_flag;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, l15 = lane & 15;
-    const int s0 = blockIdx.x * 32;
-    const int ncap = n;      // rows of the scratch (request mode: n becomes the number of requests below)
-    const int ht = blockIdx.y * (FC_UNITS / 16) + (w & 3);   // 16-row hidden tile 0..15
-    const int stt = w >> 2;                                   // 16-state tile of the 32
-    static_assert(FC_UNITS == 64, "eight waves = four hidden tiles x two state tiles");
-    const float4* W = reinterpret_cast<const float4*>(prep + PREP_W1) + (size_t)ht * 112 * 64 + lane;
-    f32x4 acc0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc0[r] = P[OFF_F1B + 16 * ht + kk * 4 + r];
-    // staging: 32 rows x FC_KC floats per chunk, FC_KC/4 threads per row, 16-byte pieces
-    constexpr int TPR = FC_KC / 4, RPP = 512 / TPR, NPASS = 32 / RPP;
-    const int row0 = threadIdx.x / TPR, c4 = (threadIdx.x % TPR) * 4;
-    // The activations of chunk c + 2 are requested while chunk c is multiplied (two register sets): a tile's rows were written
-    // by convolution waves all over the chip, so they come from beyond this XCD's L2, and one chunk of MFMAs (under 2 us) does
-    // not cover that round trip.
-    float4 st[2][NPASS];
-    auto gload = [&](int chunk) {
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            // (bounded by the rows of the scratch, not by the request count: a row past the requests holds an earlier launch's
-            // finite values and its outputs are never delivered - and the loads need not wait for the count.  Kept as a
-            // select: a plain 16-byte copy into the array sent the whole array to scratch memory.)
-            const int sa = s0 + row0 + RPP * i;
-            st[chunk & 1][i] = (sa < ncap) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * FC_KC + c4)
-                                           : make_float4(0, 0, 0, 0);
-        }
-    };
-    auto lstore = [&](int chunk) {
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i)
-            *reinterpret_cast<float4*>(&bt[chunk & 1][(row0 + RPP * i) * FC_PITCH + c4]) = st[chunk & 1][i];
-    };
-    constexpr int NCH = A3 / FC_KC;   // chunks of FC_KC k = FC_KC/4 MFMA steps = FC_KC/16 weight quads
-    constexpr int QPC = FC_KC / 16;
-    // weights: a ring of WRING groups of four quads (16 MFMA steps each), the group WRING - 1 ahead requested while a group is
-    // multiplied (measured, r04 calls C-E per launch of ~60 tiles: chunk-deep weights without the LDS pipeline 45 us, with it
-    // 35 us at 178 registers and one workgroup per CU; a ring of three groups 45 us again - the weights need the longer lead
-    // when nothing else is resident to cover it)
-    constexpr int GRP = 16, NGRP = FC_KC / 4 / GRP;
-    static_assert(QPC == 4 * NGRP, "a group = four weight quads");
-    float4 wring[WRING][4];
-    auto wload = [&](int G) {          // G = chunk * NGRP + group
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wring[G % WRING][q] = W[((size_t)G * 4 + q) * 64];
-    };
-    gload(0);
-    gload(1);
-#pragma unroll
-    for (int G0 = 0; G0 < WRING - 1; ++G0) wload(G0);
-    // (the first activations and weights are on their way while the request list is read)
+    const int s0 = blockIdx.x * ROWS;
     int my_slot = 0;
     if (rq.list) {
-        // rows = dense positions of the request list; a tile past its end has nothing to do (both of its workgroups leave)
+        // rows = dense positions of the request list; a tile past its end has nothing to do (all of its workgroups leave,
+        // before they have asked the memory system for anything else)
         const int incl = req_prefix(rq, lane, n);
         if (s0 >= n) return;
         if (w == 0) {
-            // lane j < 32 resolves row j (all 32 list entries in flight together; the slot is needed after the K loop only)
-            const int p = min(s0 + (lane & 31), n - 1);
+            // lane j resolves row j (all list entries in flight together; the slot is needed after the K loop only)
+            const int p = min(s0 + (lane & (ROWS - 1)), n - 1);
             int sg = 0;
             for (int k = 0; k < rq.segs; ++k) sg += __builtin_amdgcn_readlane(incl, k) <= p ? 1 : 0;     // first segment whose inclusive prefix exceeds p
             const int before = __shfl(incl, sg > 0 ? sg - 1 : 0, 64);
@@ -337,19 +290,66 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
             my_slot = rq.list[(sg + rq.segs * (d / rq.slots)) * rq.slots + d % rq.slots].x;
         }
     }
+    static_assert(FC_UNITS == 64 && ROWS <= 64, "eight waves = four hidden tiles x two groups of state tiles; one lane per row");
+    const int ht = blockIdx.y * (FC_UNITS / 16) + (w & 3);   // 16-row hidden tile 0..15
+    const int st0 = (w >> 2) * NST;                           // this wave's first 16-state tile
+    const float4* W = reinterpret_cast<const float4*>(prep + PREP_W1) + (size_t)ht * 112 * 64 + lane;
+    f32x4 acc[NST];
+#pragma unroll
+    for (int t = 0; t < NST; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = P[OFF_F1B + 16 * ht + kk * 4 + r];
+    // staging: ROWS rows x KC floats per chunk, KC/4 threads per row, 16-byte pieces
+    constexpr int TPR = KC / 4, RPP = 512 / TPR, NPASS = ROWS / RPP;
+    const int row0 = threadIdx.x / TPR, c4 = (threadIdx.x % TPR) * 4;
+    // The activations of chunk c + 2 are requested while chunk c is multiplied (two register sets): a tile's rows were written
+    // by convolution waves all over the chip, so they come from beyond this XCD's L2, and one chunk of MFMAs (under 2 us) does
+    // not cover that round trip.  (Kept as a select: a plain 16-byte copy into the array sent the whole array to scratch
+    // memory - tests/test_abi.py holds every hot kernel to a private segment of 0.)
+    float4 st[2][NPASS];
+    auto gload = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int sa = s0 + row0 + RPP * i;
+            st[chunk & 1][i] = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * KC + c4)
+                                        : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i)
+            *reinterpret_cast<float4*>(&bt[chunk & 1][(row0 + RPP * i) * PITCH + c4]) = st[chunk & 1][i];
+    };
+    constexpr int NCH = A3 / KC;          // chunks of KC k = KC/4 MFMA steps
+    // a group = GRP MFMA steps (per state tile) = GRP/4 weight quads; weights: a ring of WRING groups, the group WRING - 1 ahead
+    // requested while a group is multiplied (measured, r04 calls C-E per launch of ~60 32-state tiles: chunk-deep weights without
+    // the LDS pipeline 45 us, with it 35 us; a ring of three groups 45 us again - the weights need the longer lead when nothing
+    // else is resident to cover it)
+    constexpr int GRP = 16 / NST, QPG = GRP / 4, NGRP = KC / 4 / GRP;
+    static_assert(A3 % KC == 0 && NCH >= 2 && (KC / 4) % GRP == 0, "chunking");
+    float4 wring[WRING][QPG];
+    auto wload = [&](int G) {          // G = chunk * NGRP + group
+#pragma unroll
+        for (int q = 0; q < QPG; ++q) wring[G % WRING][q] = W[((size_t)G * QPG + q) * 64];
+    };
+    gload(0);
+    gload(1);
+#pragma unroll
+    for (int G0 = 0; G0 < WRING - 1; ++G0) wload(G0);
     lstore(0);
     __syncthreads();
-    static_assert(NCH >= 2, "two chunks in flight");
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const float* b0 = &bt[c & 1][(16 * stt + l15) * FC_PITCH + kk];
-        // The B operands (LDS) of the next 16 MFMA steps are requested while this group's 16 MFMAs issue (r03 - r04 call C:
+        const float* b0 = &bt[c & 1][(16 * st0 + l15) * PITCH + kk];
+        // The B operands (LDS) of the next group of MFMA steps are requested while this group's MFMAs issue (r03 - r04 call C:
         // the compiler's own order was read, wait for it, two MFMAs, read ...: an LDS round trip per pair of MFMAs, 45 us per
         // launch whatever the number of tiles, against 12 us of matrix-core time).
-        float bb[2][GRP];
+        float bb[2][NST][GRP];
         auto load_b = [&](int grp, int buf) {
 #pragma unroll
-            for (int i = 0; i < GRP; ++i) bb[buf][i] = b0[4 * (GRP * grp + i)];
+            for (int t = 0; t < NST; ++t)
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) bb[buf][t][i] = b0[16 * t * PITCH + 4 * (GRP * grp + i)];
         };
         load_b(0, 0);
 #pragma unroll
@@ -362,11 +362,13 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
                 const float4 w4 = wring[G % WRING][i / 4];
                 const int r = i & 3;
                 const float a = (r == 0) ? w4.x : (r == 1) ? w4.y : (r == 2) ? w4.z : w4.w;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[gq & 1][i], acc0, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NST; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[gq & 1][t][i], acc[t], 0, 0, 0);
             }
             // issue order inside the group: an LDS read behind every other MFMA (the reads pair up into ds_read2_b32)
 #pragma unroll
-            for (int i = 0; i < GRP / 2; ++i) {
+            for (int i = 0; i < NST * GRP / 2; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
@@ -379,23 +381,22 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     // D[i = kk*4 + r][j = l15]: four consecutive hidden units of one state per lane -> one 16-byte write-through store,
     // and a copy into LDS (hs[state][hidden unit], the layout the output layer below reads)
     const int i0 = 16 * ht + kk * 4;
-    float* hs = &bt[0][0];                      // 32 x HS_PITCH floats: the K loop is over, its staging buffers are free
-    constexpr int HS_PITCH = HID + 4;
-    static_assert(32 * HS_PITCH <= 2 * 32 * FC_PITCH, "hidden tile fits the staging buffers");
-    {
+    float* hs = &bt[0][0];                      // ROWS x HS_PITCH floats: the K loop is over, its staging buffers are free
+    static_assert(ROWS * HS_PITCH <= 2 * BT, "hidden tile fits the staging buffers");
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
         f32x4v o0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o0[r] = acc0[r] > 0.f ? acc0[r] : 0.f;
-        const int row = 16 * stt + l15;
+        for (int r = 0; r < 4; ++r) o0[r] = acc[t][r] > 0.f ? acc[t][r] : 0.f;
+        const int row = 16 * (st0 + t) + l15;
         if (s0 + row < n) {
             float* dst = hout + (size_t)(s0 + row) * hstride + i0;
             asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(o0) : "memory");
         }
         *reinterpret_cast<f32x4v*>(&hs[row * HS_PITCH + i0]) = o0;
     }
-    if (rq.list && w == 0 && lane < 32) row_slot[lane] = my_slot;      // (the list entry has had the whole K loop to arrive)
+    if (rq.list && w == 0 && lane < ROWS) row_slot[lane] = my_slot;      // (the list entry has had the whole K loop to arrive)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __shared__ int last_flag;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int old = __hip_atomic_fetch_add(&cnt[(size_t)blockIdx.x * cnt_stride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -404,16 +405,17 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     }
     __syncthreads();
     if (last_flag != FC_NY - 1) return;
-    // ---- this workgroup arrived last: the other parts of h past the caches (32 states x 192 units = 1536 x 16 bytes) ----
-    {
+    // ---- this workgroup arrived last: the other parts of h past the caches (ROWS states x 192 units) ----
+#pragma unroll
+    for (int pass = 0; pass < NST; ++pass) {
         // three 16-byte loads per thread in flight together, one wait
-        const int e = threadIdx.x, row = e >> 4, c4 = (e & 15) * 4;
+        const int e = threadIdx.x, row = 32 * pass + (e >> 4), c4h = (e & 15) * 4;
         f32x4v wv[FC_NY - 1];
         const bool in = s0 + row < n;
 #pragma unroll
         for (int it = 0; it < FC_NY - 1; ++it) {
             const int part = it + (it >= (int)blockIdx.y ? 1 : 0);      // the quarters that are not this workgroup's
-            const float* src = hout + (size_t)(s0 + (in ? row : 0)) * hstride + part * FC_UNITS + c4;
+            const float* src = hout + (size_t)(s0 + (in ? row : 0)) * hstride + part * FC_UNITS + c4h;
             asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(wv[it]) : "v"(src) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]) :: "memory");
@@ -421,24 +423,24 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
 #pragma unroll
         for (int it = 0; it < FC_NY - 1; ++it) {
             const int part = it + (it >= (int)blockIdx.y ? 1 : 0);
-            if (in) *reinterpret_cast<f32x4v*>(&hs[row * HS_PITCH + part * FC_UNITS + c4]) = wv[it];
+            if (in) *reinterpret_cast<f32x4v*>(&hs[row * HS_PITCH + part * FC_UNITS + c4h]) = wv[it];
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-        // one chain per lane: state j = lane >> 1, output o = lane & 1 (k_fc_out's thread t = 2 s + o); fma over the 256
-        // hidden units in order
+    if (threadIdx.x < 2 * ROWS) {
+        // one chain per lane: state j = t >> 1, output o = t & 1 (k_fc_out's thread t = 2 s + o); fma over the 256 hidden units
+        // in order
         const int j = threadIdx.x >> 1, o = threadIdx.x & 1;
         int sidx = s0 + j;
         const bool live = sidx < n;
         if (rq.list) sidx = row_slot[j];          // (written by wave 0 before the barrier above)
         if (live) {
-            float acc = P[OFF_FOB + o];
+            float a = P[OFF_FOB + o];
             const float* x = &hs[j * HS_PITCH];
             const float* wr = P + OFF_FOW + o * HID;
 #pragma unroll 8
-            for (int i = 0; i < HID; ++i) acc = fmaf(x[i], wr[i], acc);
-            const double e = tm_exp(-(double)acc);
+            for (int i = 0; i < HID; ++i) a = fmaf(x[i], wr[i], a);
+            const double e = tm_exp(-(double)a);
             const float sg = (float)(1.0 / (1.0 + e));
             const float tt = sg * P[OFF_UB + o];
             const float res = tt + P[OFF_LB + o];
@@ -498,10 +500,10 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, rq,
                        max_nodes, n, scratch, SS);
     if (n >= 8192)      // (request slots: the leaf-parallel kinds' seven per game)
-        hipLaunchKernelGGL(k_vn_fc1<3>, dim3((n + 31) / 32, FC_NY), dim3(512), 0, stream, P, prepared, scratch, SS, n,
-                           scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
+        hipLaunchKernelGGL((k_vn_fc1<2, 128, 3>), dim3((n + 63) / 64, FC_NY), dim3(512), 0, stream, P, prepared, scratch, SS, n,
+                           scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 64 * SS, v, var);
     else
-        hipLaunchKernelGGL(k_vn_fc1<6>, dim3((n + 31) / 32, FC_NY), dim3(512), 0, stream, P, prepared, scratch, SS, n,
+        hipLaunchKernelGGL((k_vn_fc1<1, 256, 6>), dim3((n + 31) / 32, FC_NY), dim3(512), 0, stream, P, prepared, scratch, SS, n,
                            scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
     return (int)hipGetLastError();
 }
