@@ -45,10 +45,11 @@ def pmc_traffic(kernels, workload_key, fetch_scale=1.0):
         return None
     tot = 0.0
     for name in kernels:
-        e = doc["kernels"].get(name)
-        if not e or "FETCH_SIZE_KB_mean" not in e or "WRITE_SIZE_KB_mean" not in e:
+        # (a kernel template is listed with its arguments, e.g. k_vn_fc1<1, 256, 6>: one instantiation runs per workload)
+        es = [e for k, e in doc["kernels"].items() if k == name or k.startswith(name + "<")]
+        if len(es) != 1 or "FETCH_SIZE_KB_mean" not in es[0] or "WRITE_SIZE_KB_mean" not in es[0]:
             return None
-        tot += 1024.0 * (fetch_scale * e["FETCH_SIZE_KB_mean"] + e["WRITE_SIZE_KB_mean"])
+        tot += 1024.0 * (fetch_scale * es[0]["FETCH_SIZE_KB_mean"] + es[0]["WRITE_SIZE_KB_mean"])
     return tot
 
 
