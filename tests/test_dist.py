@@ -217,3 +217,54 @@ def test_data_parallel_training_rejects_unequal_shards():
         T.check_data_parallel_batch(1025, 8)
     with pytest.raises(ValueError):
         T.check_data_parallel_batch(4, 8)       # a rank would get an empty shard
+
+
+def _rows(rank):
+    rng = np.random.default_rng(700 + rank)
+    n = [4, 0, 7][rank % 3] + rank
+    keys = torch.from_numpy(rng.integers(-2**31, 2**31 - 1, size=(n, 12), dtype=np.int64).astype(np.int32))
+    d = rng.random((n, 64)).astype(np.float32)
+    d[:, 50:] = 0
+    return keys, torch.from_numpy(d), torch.from_numpy(rng.integers(8, 400, size=n).astype(np.float32))
+
+
+def _rows_worker(rank, world, port, q):
+    """the distributional agent's exchange + fit: harvested (observation, distribution, visits) rows of unequal counts per rank
+    -> the same union on every rank -> the same data-parallel fit of the head (model_distributional.Model_Dist) on every rank"""
+    import torch.distributed as dist
+    from tetris_mcts_amd import dist as tdist
+    from tetris_mcts_amd.model_distributional import Model_Dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    k, d, v = _rows(rank)
+    ka, da, va = tdist.all_gather_rows(k, d, v)
+    m = Model_Dist(atoms=50, device="cpu", seed=4, backend="torch")
+    n = ka.shape[0]
+    states = torch.zeros(n, 1, 22, 10)
+    states[:, :, 2:, :] = tdist.render_observations(ka)
+    tgt = da[:, :50] / da[:, :50].sum(1, keepdim=True)
+    m.train_data([states, tgt, va.reshape(-1, 1)], batch_size=8, iters_per_val=5, max_iters=10, log=False, validation_fraction=0.0)
+    flat = torch.cat([p.detach().reshape(-1) for p in m.model.parameters()])
+    q.put((rank, ka.numpy(), da.numpy(), va.numpy(), flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_rows_and_distributional_fit_gloo_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = [np.concatenate([_rows(r)[i].numpy() for r in range(world)]) for i in range(3)]
+    for r in res:
+        assert np.array_equal(r[1], exp[0]) and r[2].tobytes() == exp[1].tobytes() and r[3].tobytes() == exp[2].tobytes()
+    assert res[0][4].tobytes() == res[1][4].tobytes()          # the replicas took the same steps
