@@ -399,6 +399,10 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        // (relaxed on purpose: the hand-off is carried by the write-through sc1 stores + s_waitcnt before the arrival and the sc1
+        // loads after it - MI355X_MICROARCH.md's measured form.  With __ATOMIC_ACQ_REL here the compiler adds buffer_wbl2 sc1 /
+        // buffer_inv sc1 around the atomic: 33.4 -> 35.8 us per launch, r04; tests/test_gpu_valuenet.py holds the folded output
+        // layer to the oracle's bits on every run)
         const int old = __hip_atomic_fetch_add(&cnt[(size_t)blockIdx.x * cnt_stride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = old;
         if (old == FC_NY - 1) __hip_atomic_store(&cnt[(size_t)blockIdx.x * cnt_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
