@@ -24,13 +24,13 @@ def _make(name, G, sims, max_nodes, seed, evaluator=None, model=None, **kw):
 
 
 def _compare_run(oracle, name, G, sims, max_nodes, seed, moves, evaluator, params=None, model=None, env_args=None,
-                 check_tree_every=0, **agent_kw):
+                 check_tree_every=0, okind=None, out=None, **agent_kw):
     env_args = env_args or ((20, 10), 1, 0, 0)
     game, agent = _make(name, G, sims, max_nodes, seed, evaluator=hash_eval_torch if evaluator == "hash" else None,
                         model=model, env_args=env_args, **agent_kw)
     og = [oracle.Game(env_args[1], env_args[2], env_args[3], seed + g) for g in range(G)]
-    oa = [oracle.Agent(KIND[name], max_nodes=max_nodes, app=env_args[1], scoring=env_args[2], randomizer=env_args[3],
-                       evaluator=evaluator, params=params) for _ in range(G)]
+    oa = [oracle.Agent(KIND[name] if okind is None else okind, max_nodes=max_nodes, app=env_args[1], scoring=env_args[2],
+                       randomizer=env_args[3], evaluator=evaluator, params=params) for _ in range(G)]
     for g in range(G):
         oa[g].update_root(og[g])
     for m in range(moves):
@@ -70,6 +70,8 @@ def _compare_run(oracle, name, G, sims, max_nodes, seed, moves, evaluator, param
     gcs = sum(o.n_gc for o in oa)
     assert agent.store.counter("N_GC") == gcs
     assert agent.store.counter("N_EXPAND") == sum(o.n_expand for o in oa)
+    if out is not None:
+        out.update(agent=agent, oracles=oa)
     return gcs
 
 
@@ -135,6 +137,29 @@ def test_value_net_in_the_loop(oracle, golden_dir, name, sims, moves):
     model.set_flat_params(params)
     _compare_run(oracle, name, G=4, sims=sims, max_nodes=100000, seed=13, moves=moves, evaluator="valuenet",
                  params=params, model=model)
+
+
+@pytest.mark.parametrize("max_nodes,moves", [(100000, 10), (6000, 40)])
+def test_cpp_single_leaf_agent_in_the_native_loop(oracle, golden_dir, max_nodes, moves):
+    """The all-C++ agent without leaf parallelism (agent.cpp:437-446,496-513; TM_KIND_CPPAGENT) with the HIP value net through the
+    native launch loop - the other kind whose leaves are answered from the per-observation cache (TM_SIM_EVAL_NEEDED) - against
+    oracle kind 3, which evaluates every leaf: same actions, statistics and trees, and as many cache answers as the oracle
+    counts repeated observations; with a small pool through collections (a freed observation's cache entry is reset when the
+    slot is handed out again)."""
+    from tetris_mcts_amd.model import Model_VV
+    params = np.load(os.path.join(golden_dir, "ref_valuenet.npz"))["params"]
+    model = Model_VV(backend="hip")
+    model.set_flat_params(params)
+    out = {}
+    gcs = _compare_run(oracle, "ValueSimC", G=4, sims=60, max_nodes=max_nodes, seed=77, moves=moves, evaluator="valuenet",
+                       params=params, model=model, okind=3, out=out, leaf_parallel=False, check_tree_every=moves)
+    agent, oa = out["agent"], out["oracles"]
+    assert agent.search_model() is model and agent.store.kind == 3
+    cached, posted = agent.store.counter("N_EVAL_CACHED"), agent.store.counter("N_EVAL")
+    assert cached == sum(o.n_eval_repeat for o in oa) and cached > 0
+    assert posted + cached == sum(o.n_eval_states for o in oa)
+    if max_nodes < 10000:
+        assert gcs >= 4
 
 
 @pytest.mark.parametrize("idx", [0, 1, 2, 3])
