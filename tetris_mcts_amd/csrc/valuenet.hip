@@ -242,32 +242,36 @@ __device__ __forceinline__ int req_at(const ReqList& rq, int incl, int p, int la
 
 // fc1 (1792 -> 256) + ReLU on v_mfma_f32_16x16x4_f32 (D[16x16] += A[16x4] B[4x16]; lane l: A[i=l&15][k=l>>4],
 // B[k=l>>4][j=l&15], D[i=(l>>4)*4+r][j=l&15]; per output a k-ordered fma chain, 4 terms per instruction).
-// A workgroup of 8 waves owns a tile of ROWS = 32 NST states x 64 hidden units (FC_NY = 4 workgroups per tile): wave w the
-// 16-row hidden tile 4 blockIdx.y + (w & 3) and the NST 16-state tiles (w >> 2) NST ..., two waves per SIMD so one wave's
-// waits hide behind the other's MFMAs.  Activations are staged through LDS in KC-wide K chunks (requested two chunks ahead),
-// the B operands read from LDS a group of steps ahead, the weights held in a ring of WRING groups.  Two shapes, the same
-// arithmetic and the same bits (every output element is its own k-ordered chain whatever the tiling):
-//   <1, 256, 6>  32-state tiles, 152 registers, one workgroup per CU: the single-leaf kinds, whose dense request list leaves
-//                60-100 tiles a launch - a latency problem (r03 gave a tile two workgroups of 128 units: half of the CUs
-//                without a workgroup, 40 us whatever the number of tiles; r04 calls B-G: 51 -> 35 us);
-//   <2, 128, 3>  64-state tiles, two workgroups per CU: the leaf-parallel kinds' hundreds of tiles - an L2-bandwidth problem
-//                (every tile streams the 1.8 MB of weights: twice the states per tile = half the stream).
+// A workgroup of 8 waves owns a tile of ROWS = 16 RT states x 256 / NY hidden units (NY workgroups per tile): wave w one
+// 16-row hidden tile and NST 16-state tiles, two waves per SIMD so one wave's waits hide behind the other's MFMAs.
+// Activations are staged through LDS in KC-wide K chunks (requested two chunks ahead), the B operands read from LDS a group
+// of steps ahead, the weights held in a ring of WRING groups.  Two shapes, the same arithmetic and the same bits (every
+// output element is its own k-ordered chain whatever the tiling):
+//   <2, 4, 256, 6>  32-state tiles, four workgroups of 64 units each, 152 registers, one workgroup per CU: the single-leaf
+//                   kinds, whose dense request list leaves 60-100 tiles a launch - a latency problem (r03 gave a tile two
+//                   workgroups of 128 units: half of the CUs without a workgroup, 40 us whatever the number of tiles; r04 calls
+//                   B-G: 51 -> 33 us);
+//   <4, 4, 128, 3>  64-state tiles, four workgroups of 64 units each, two workgroups per CU: the leaf-parallel kinds' hundreds
+//                   of tiles - an L2-bandwidth problem (every tile streams the 1.8 MB of weights: twice the states per tile =
+//                   half the stream).  (<4, 2, 128, 3>, two workgroups of 128 units per tile, reads the activations half as
+//                   often and was measured at 121 us against 80: 224 workgroups of four dependent accumulators each.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// The output layer (256 -> 2, sigmoid, affine) is folded in: a tile's FC_NY workgroups (quarters of the hidden units) store
+// The output layer (256 -> 2, sigmoid, affine) is folded in: a tile's NY workgroups (parts of the hidden units) store
 // their part of h with write-through (sc1) stores, wait for them, and arrive on the tile's counter; the LAST to arrive reads
 // the other parts with sc1 loads (the valid hand-off form of MI355X_MICROARCH.md: 16-byte sc1 stores and loads, no fences)
 // and runs the 2 x 256 fma chains of its states - the same chain, in the same order, as k_fc_out.  Nobody waits for
 // anybody.  `cnt`: one int per tile (the first pad word of the scratch row of the tile's first state), zero before the first
 // launch (the kernel leaves it zero).
-constexpr int FC_NY = 4, FC_UNITS = HID / FC_NY;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int NST, int KC, int WRING>
+template <int RT, int NY, int KC, int WRING>
 __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
                                                 float* __restrict__ hout, int hstride,
                                                 ReqList rq, int32_t* __restrict__ cnt, int cnt_stride,
                                                 float* __restrict__ v_out, float* __restrict__ var_out) {
-    constexpr int ROWS = 32 * NST, PITCH = KC + 4, HS_PITCH = HID + 4;
+    constexpr int ROWS = 16 * RT, PITCH = KC + 4, HS_PITCH = HID + 4;
+    constexpr int UNITS = HID / NY, HT = UNITS / 16, SG = 8 / HT, NST = RT / SG;      // hidden tiles per workgroup, groups of state tiles, state tiles per wave
+    static_assert(HT * SG == 8 && NST * SG == RT && NST >= 1 && ROWS <= 64, "eight waves = hidden tiles x groups of state tiles; one lane per row");
     constexpr int BT = ROWS * PITCH > (ROWS * HS_PITCH + 1) / 2 ? ROWS * PITCH : (ROWS * HS_PITCH + 1) / 2;     // floats per staging buffer
     __shared__ __attribute__((aligned(16))) float bt[2][BT];
     __shared__ int row_slot[ROWS];        // request mode: where row j of the tile delivers its outputs
@@ -290,9 +294,8 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
             my_slot = rq.list[(sg + rq.segs * (d / rq.slots)) * rq.slots + d % rq.slots].x;
         }
     }
-    static_assert(FC_UNITS == 64 && ROWS <= 64, "eight waves = four hidden tiles x two groups of state tiles; one lane per row");
-    const int ht = blockIdx.y * (FC_UNITS / 16) + (w & 3);   // 16-row hidden tile 0..15
-    const int st0 = (w >> 2) * NST;                           // this wave's first 16-state tile
+    const int ht = blockIdx.y * HT + (w % HT);       // 16-row hidden tile 0..15
+    const int st0 = (w / HT) * NST;                   // this wave's first 16-state tile
     const float4* W = reinterpret_cast<const float4*>(prep + PREP_W1) + (size_t)ht * 112 * 64 + lane;
     f32x4 acc[NST];
 #pragma unroll
@@ -405,29 +408,31 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
         // layer to the oracle's bits on every run)
         const int old = __hip_atomic_fetch_add(&cnt[(size_t)blockIdx.x * cnt_stride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = old;
-        if (old == FC_NY - 1) __hip_atomic_store(&cnt[(size_t)blockIdx.x * cnt_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        if (old == NY - 1) __hip_atomic_store(&cnt[(size_t)blockIdx.x * cnt_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
     }
     __syncthreads();
-    if (last_flag != FC_NY - 1) return;
-    // ---- this workgroup arrived last: the other parts of h past the caches (ROWS states x 192 units) ----
+    if (last_flag != NY - 1) return;
+    // ---- this workgroup arrived last: the other parts of h past the caches (ROWS states x (256 - UNITS) units) ----
+    {
+        // all of a thread's 16-byte loads in flight together, one wait (the memory clobbers keep the LDS stores behind it)
+        constexpr int OQ = (HID - UNITS) / 4, CNT = ROWS * OQ / 512;      // 16-byte pieces per row of the other parts; per thread
+        static_assert(ROWS * OQ % 512 == 0, "whole passes");
+        f32x4v wv[CNT];
 #pragma unroll
-    for (int pass = 0; pass < NST; ++pass) {
-        // three 16-byte loads per thread in flight together, one wait
-        const int e = threadIdx.x, row = 32 * pass + (e >> 4), c4h = (e & 15) * 4;
-        f32x4v wv[FC_NY - 1];
-        const bool in = s0 + row < n;
-#pragma unroll
-        for (int it = 0; it < FC_NY - 1; ++it) {
-            const int part = it + (it >= (int)blockIdx.y ? 1 : 0);      // the quarters that are not this workgroup's
-            const float* src = hout + (size_t)(s0 + (in ? row : 0)) * hstride + part * FC_UNITS + c4h;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(wv[it]) : "v"(src) : "memory");
+        for (int i = 0; i < CNT; ++i) {
+            const int e = i * 512 + threadIdx.x, row = e / OQ, c = (e % OQ) * 4;
+            const int col = c < (int)blockIdx.y * UNITS ? c : c + UNITS;      // skipping this workgroup's own units
+            const float* src = hout + (size_t)(s0 + (s0 + row < n ? row : 0)) * hstride + col;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(wv[i]) : "v"(src) : "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]) :: "memory");
-        static_assert(FC_NY == 4, "three other parts");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int it = 0; it < FC_NY - 1; ++it) {
-            const int part = it + (it >= (int)blockIdx.y ? 1 : 0);
-            if (in) *reinterpret_cast<f32x4v*>(&hs[row * HS_PITCH + part * FC_UNITS + c4h]) = wv[it];
+        for (int i = 0; i < CNT; ++i) {
+            const int e = i * 512 + threadIdx.x, row = e / OQ, c = (e % OQ) * 4;
+            const int col = c < (int)blockIdx.y * UNITS ? c : c + UNITS;
+            f32x4v t = wv[i];
+            asm volatile("" : "+v"(t));          // (a use the compiler cannot hoist above the wait)
+            if (s0 + row < n) *reinterpret_cast<f32x4v*>(&hs[row * HS_PITCH + col]) = t;
         }
     }
     __syncthreads();
@@ -504,10 +509,10 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, rq,
                        max_nodes, n, scratch, SS);
     if (n >= 8192)      // (request slots: the leaf-parallel kinds' seven per game)
-        hipLaunchKernelGGL((k_vn_fc1<2, 128, 3>), dim3((n + 63) / 64, FC_NY), dim3(512), 0, stream, P, prepared, scratch, SS, n,
+        hipLaunchKernelGGL((k_vn_fc1<4, 4, 128, 3>), dim3((n + 63) / 64, 4), dim3(512), 0, stream, P, prepared, scratch, SS, n,
                            scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 64 * SS, v, var);
     else
-        hipLaunchKernelGGL((k_vn_fc1<1, 256, 6>), dim3((n + 31) / 32, FC_NY), dim3(512), 0, stream, P, prepared, scratch, SS, n,
+        hipLaunchKernelGGL((k_vn_fc1<2, 4, 256, 6>), dim3((n + 31) / 32, 4), dim3(512), 0, stream, P, prepared, scratch, SS, n,
                            scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
     return (int)hipGetLastError();
 }
