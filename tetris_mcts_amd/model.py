@@ -65,7 +65,7 @@ class Model_VV:
         self._flat = None
         self._prepared = None
         self.weights_epoch = next_weights_epoch()
-        self._scratch = None         # "hip": zero-filled rows of SCRATCH_MFMA floats (k_vn_fc1 keeps a counter per 32 states in them)
+        self._scratch = None         # "hip": zero-filled rows of SCRATCH_MFMA floats (k_vn_fc1 keeps a counter per tile of states in them)
         self._scratch_plain = None   # "hip_plain": its own buffer - never handed to the matrix-core kernels
 
     def training(self, mode=True):
