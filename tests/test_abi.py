@@ -203,3 +203,39 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
                 seen.add(next(h for h in hot if h in name))
                 assert int(scratch) == 0 and int(spills) == 0, (name, scratch, spills)
     assert seen == set(hot), seen
+
+
+def test_dense_request_list_addressing():
+    """The dense request list of include/tetris_mcts_hip.h (tm_store::eval_list): game g appends to segment g % segs, entry d
+    of segment s lives at (s + segs * (d / slots)) * slots + d % slots; the consumers (valuenet.hip req_prefix / req_at) count
+    dense positions through the segments in order.  A model of both sides: every posted request is found exactly once, inside
+    the slots of its segment's games, whatever the numbers of games, slots and requests."""
+    rng = np.random.default_rng(7)
+    for n_games, slots in ((1, 1), (3, 7), (64, 1), (100, 7), (4096, 1), (4096, 7), (777, 7)):
+        segs = min(n_games, 64)
+        posted = [int(rng.integers(0, slots + 1)) if rng.random() < 0.7 else 0 for _ in range(n_games)]
+        cnt = [0] * segs
+        lst = {}
+        for g in rng.permutation(n_games):                       # the waves finish in any order
+            k = posted[g]
+            if k == 0:
+                continue
+            sg = g % segs
+            base = cnt[sg]
+            cnt[sg] += k
+            for i in range(k):
+                d = base + i
+                at = (sg + segs * (d // slots)) * slots + d % slots
+                assert 0 <= at < n_games * slots and at not in lst, (n_games, slots, g, at)
+                assert (at // slots) % segs == sg                 # inside the slots of one of this segment's games
+                lst[at] = (int(g) * slots + i)
+        incl = np.cumsum(cnt)
+        total = int(incl[-1])
+        assert total == sum(posted)
+        seen = set()
+        for p in range(total):
+            sg = int(np.sum(incl <= p))
+            d = p - (int(incl[sg - 1]) if sg else 0)
+            at = (sg + segs * (d // slots)) * slots + d % slots
+            seen.add(lst[at])
+        assert len(seen) == total

@@ -154,3 +154,45 @@ def test_oracle_dist_agent_invariants(oracle):
     assert np.allclose(nd[seen].sum(1), 1.0, atol=2e-5)
     assert np.all(ns[occ, 2] == arr["score"][occ])            # node_stats[:, 2] is the node's score
     assert np.all(ns[seen, 3] >= 0)
+
+
+def test_store_nodes_dist_follows_the_reference_text(oracle):
+    """oracle kind 6's harvest (agent_oracle.c store_nodes_dist) against the reference's commented store_nodes
+    (agents/DistValueSimOnline.py:116-141) applied literally, in Python, to the oracle's own arrays: `for idx in nodes: if
+    ns[0] < min_visits or any(n_stats[child[idx][i]][0] < 1 ...): continue; states[m] = g_arr[idx].getState(); values[m] =
+    n_dist[idx]; weights[m] = ns[0]` with nodes = the nodes a collection removes, ascending."""
+    min_visits = 6
+    g = oracle.Game(seed=2024)
+    a = oracle.Agent(6, max_nodes=4000, low=5, online=True, min_visits_to_store=min_visits, memory_size=50000)
+    a.update_root(g)
+    checked = 0
+    for m in range(40):
+        act = a.play(120)
+        g.play(act)
+        a.update_root(g)
+        if g.end:
+            g.reset()
+            a.update_root(g)
+        # an explicit collection: what it stores must be what the reference's text selects from the state just before it
+        ref = a.arrays()
+        child, games = ref["child"].copy(), ref["games"].copy()
+        ns, nd = (x.copy() for x in a.dist_arrays())
+        mark = np.zeros(4000, np.uint8)
+        oracle.lib().orc_get_all_childs(a.root, oracle.ptr(child), 4000, oracle.ptr(mark))
+        nodes = [i for i in range(1, 4000) if not mark[i]]
+        exp_states, exp_values, exp_weights = [], [], []
+        for idx in nodes:
+            if ns[idx][0] < min_visits or any(ns[child[idx][i]][0] < 1 for i in range(7)):
+                continue
+            st = np.zeros((20, 10), np.int8)
+            oracle.lib().orc_game_render(oracle.ptr(games[idx:idx + 1]), oracle.ptr(st))
+            exp_states.append(st.reshape(200)); exp_values.append(nd[idx]); exp_weights.append(ns[idx][0])
+        before = a.memory_index
+        a.remove_nodes()
+        st, d, v = a.memory_dist()
+        assert a.memory_index - before == len(exp_weights), (m, a.memory_index - before, len(exp_weights))
+        if exp_weights:
+            assert np.array_equal(st[before:], np.stack(exp_states)) and d[before:].tobytes() == np.stack(exp_values).tobytes()
+            assert v[before:].tobytes() == np.asarray(exp_weights, np.float32).tobytes()
+            checked += len(exp_weights)
+    assert checked > 30

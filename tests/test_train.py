@@ -172,3 +172,19 @@ def test_distributional_head_fit_and_loss():
     before = float(m.loss(x, t)[0])
     m.train_data([x, t, w], batch_size=64, iters_per_val=50, max_iters=150, log=False)
     assert float(m.loss(x, t)[0]) < 0.8 * before
+
+
+def test_distributional_loss_is_the_reference_expression_where_that_is_finite():
+    """model/model_distributional.py:84-98: loss = -value * (log p - log value), summed over the atoms, mean / std over the
+    batch - identical numbers for targets without empty atoms (where the reference's expression is finite)."""
+    import torch
+    from tetris_mcts_amd.model_distributional import Model_Dist
+    torch.manual_seed(0)
+    m = Model_Dist(atoms=50, device="cpu", seed=2, backend="torch")
+    x = (torch.rand(33, 1, 22, 10) < 0.3).float()
+    t = torch.softmax(torch.randn(33, 50), 1)
+    lp = m.model.log_prob(x)
+    ref = (-t * (lp - t.log())).sum(dim=1)
+    std, mean = torch.std_mean(ref)
+    got_mean, got_std = m.loss(x, t)
+    assert torch.allclose(got_mean, mean, rtol=1e-5, atol=1e-7) and torch.allclose(got_std, std, rtol=1e-4, atol=1e-7)
