@@ -58,3 +58,29 @@ def test_pmc_traffic_summary_and_bench_reader(tmp_path, monkeypatch):
     assert bench.pmc_traffic(["tmcts::k_sim_step<false>"], "K1", 2.0) == 1024.0 * (40.0 + 6.0)
     assert bench.pmc_traffic(["tmcts::k_sim_step<false>"], "another workload") is None
     assert bench.pmc_traffic(["tmcts_vn::k_vn_conv"], "K1") is None
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The driver's line as this round's final run printed it (profiles/r04_bench_valuesim_4096x500.json): the keys of the bench
+    contract, the two objects of the hot-path tier (roofline, cpu_baseline) and this repo's additions, with consistent numbers."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_valuesim_4096x500.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port")
+    # the per-kernel figures of one simulation step times the simulations of a move fit inside the step
+    per_sim = d["roofline"]["avg_launch_ms"] + d["roofline_other"]["avg_launch_ms"]
+    assert per_sim * d["config"]["sims_per_move"] <= d["ms_per_step"]
+    # expansions per second x seconds per step = expansions per step <= games x simulations
+    assert d["value"] * d["ms_per_step"] * 1e-3 <= d["config"]["games_per_gpu"] * d["config"]["sims_per_move"]
+    assert set(d["other_configs"]) == {"ValueSimLP", "DistValueSim", "Vanilla"} and all("error" not in v or v["error"] is None for v in d["other_configs"].values())
+    assert d["steady_state"]["ms_per_step"] < 1.1 * d["ms_per_step"]        # the steady state within 10 % of the headline
