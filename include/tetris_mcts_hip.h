@@ -37,8 +37,9 @@ extern "C" {
 #define TM_GC_PART_DW 192   /* per-game scratch of a collection: (free nodes, free observations, harvested tuples) per collector workgroup */
 #define TM_VALUENET_PARAMS 478342
 #define TM_VALUENET_SCRATCH 9728       /* floats of scratch per state, tm_valuenet_forward_plain */
-#define TM_VALUENET_SCRATCH_MFMA 2064  /* floats of scratch per state, tm_valuenet_forward / _requests: ZERO-FILLED before the first call
-                                          (the kernels keep a counter per tile of 32 or 64 states in it and leave it zero) */
+#define TM_VALUENET_SCRATCH_MFMA 2064  /* floats of scratch per state, tm_valuenet_forward / _requests; no initial contents required (the
+                                          kernels keep a counter per tile of 32 or 64 states in the rows' padding: every evaluation
+                                          clears them first) */
 #define TM_VALUENET_PREPARED 477184    /* floats: conv2 + conv3 + fc1 operand streams */
 #define TM_DISTNET_PARAMS(atoms) (279232 + 129 * (atoms))  /* floats: conv1.w[32][1][4][4] conv1.b[32] conv2.w[32][32][4][4] conv2.b[32]
                                           fc1.w[128][2048] fc1.b[128] fc_v.w[atoms][128] fc_v.b[atoms] (model/model_distributional.py:33-42) */

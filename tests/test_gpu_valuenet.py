@@ -29,6 +29,14 @@ def test_hip_valuenet(oracle, golden_dir, pk, ok):
         scale = max(1.0, float(z[pk][478339]) / 1000.0)
         assert np.abs(v - ref[:, 0]).max() <= TOL * max(1.0, float(z[pk][478338]) / 100.0)
         assert np.abs(var - ref[:, 1]).max() <= TOL * scale
+    # the scratch needs no initial contents: garbage in it (the arrival counters of k_vn_fc1 live in the rows' padding) - e.g.
+    # what a launch aborted between two arrivals would leave - does not reach the outputs
+    m._scratch.view(torch.int32).random_(-2**31, 2**31 - 1)
+    v, var = m.inference_device(states[:64].contiguous())
+    ov, ovar = np.zeros(64, np.float32), np.zeros(64, np.float32)
+    oracle.lib().orc_valuenet_forward(oracle.ptr(np.ascontiguousarray(z[pk])), oracle.ptr(np.ascontiguousarray(z["states"].reshape(-1, 200)[:64])),
+                                      64, oracle.ptr(ov), oracle.ptr(ovar))
+    assert v.cpu().numpy().tobytes() == ov.tobytes() and var.cpu().numpy().tobytes() == ovar.tobytes()
     # batch invariance: a state's output does not depend on its neighbours
     big = states.repeat(40, 1)[torch.randperm(64 * 40, device="cuda")]
     v1, r1 = m.inference_device(big.contiguous())

@@ -260,8 +260,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // their part of h with write-through (sc1) stores, wait for them, and arrive on the tile's counter; the LAST to arrive reads
 // the other parts with sc1 loads (the valid hand-off form of MI355X_MICROARCH.md: 16-byte sc1 stores and loads, no fences)
 // and runs the 2 x 256 fma chains of its states - the same chain, in the same order, as k_fc_out.  Nobody waits for
-// anybody.  `cnt`: one int per tile (the first pad word of the scratch row of the tile's first state), zero before the first
-// launch (the kernel leaves it zero).
+// anybody.  `cnt`: one int per tile (the first pad word of the scratch row of the tile's first state), zeroed by k_vn_conv at
+// the start of every evaluation (the kernel also leaves it zero).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int RT, int NY, int KC, int WRING>
 __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
@@ -507,7 +507,7 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     int blocks = (n + 3) / 4;
     if (blocks > 256 * TM_CONV_WG_PER_CU) blocks = 256 * TM_CONV_WG_PER_CU;   // resident workgroups, waves stride over the states
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, rq,
-                       max_nodes, n, scratch, SS);
+                       max_nodes, n, scratch, SS, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS);
     if (n >= 8192)      // (request slots: the leaf-parallel kinds' seven per game)
         hipLaunchKernelGGL((k_vn_fc1<4, 4, 128, 3>), dim3((n + 63) / 64, 4), dim3(512), 0, stream, P, prepared, scratch, SS, n,
                            scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 64 * SS, v, var);

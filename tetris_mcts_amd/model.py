@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import _lib
 from .store import _p, _stream
 
-SCRATCH_MFMA = 2064     # TM_VALUENET_SCRATCH_MFMA (include/tetris_mcts_hip.h): floats of scratch per state, zero-filled once
+SCRATCH_MFMA = 2064     # TM_VALUENET_SCRATCH_MFMA (include/tetris_mcts_hip.h): floats of scratch per state (no initial contents required)
 PARAM_ORDER = ["head.conv1.weight", "head.conv1.bias", "head.conv2.weight", "head.conv2.bias", "head.conv3.weight",
                "head.conv3.bias", "head.fc1.weight", "head.fc1.bias", "head.fc_out.weight", "head.fc_out.bias",
                "out_ubound", "out_lbound"]
@@ -65,7 +65,7 @@ class Model_VV:
         self._flat = None
         self._prepared = None
         self.weights_epoch = next_weights_epoch()
-        self._scratch = None         # "hip": zero-filled rows of SCRATCH_MFMA floats (k_vn_fc1 keeps a counter per tile of states in them)
+        self._scratch = None         # "hip": rows of SCRATCH_MFMA floats (k_vn_fc1's per-tile counters live in their padding; every evaluation clears them)
         self._scratch_plain = None   # "hip_plain": its own buffer - never handed to the matrix-core kernels
 
     def training(self, mode=True):
