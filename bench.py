@@ -397,6 +397,9 @@ def main():
     ap.add_argument("--others", default="auto", choices=["auto", "none", "all"],
                     help="short lines of the other BASELINE configs (ValueSimLP, DistValueSim at 1000 sims, Vanilla at 100 sims) "
                     "inside the headline's; auto = when this is the default single-GPU ValueSim run")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="all ranks on cuda:0 with the gloo backend (payloads staged through host memory): exercises the multi-rank "
+                    "code path on a one-GPU box; size --games so that all ranks' stores fit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the N-process CPU baseline (0: all host cores, at most 128)")
@@ -406,16 +409,37 @@ def main():
     import torch
     import torch.distributed as dist
 
+    launched = "RANK" in os.environ      # torch.distributed.run: a process group (RCCL), even for one rank
+    n_dev = torch.cuda.device_count()
+    if args.gpus > 1 and not args.share_gpu and n_dev < args.gpus:
+        sys.exit("bench.py --gpus %d needs %d visible GPUs, this box has %d (one process per GPU; --share-gpu puts the ranks "
+                 "on one device with the gloo backend: a functional check of the multi-rank path, not a measurement)"
+                 % (args.gpus, args.gpus, n_dev))
+    if not launched and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks of this same command line (the driver's N > 1 form,
+        # `python -m torch.distributed.run ... bench.py --gpus N`, comes in with RANK set and skips this)
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d was launched as %d rank(s): --nproc-per-node must equal --gpus" % (args.gpus, world))
     torch.cuda.set_device(local)
-    launched = "RANK" in os.environ      # torch.distributed.run: a process group (RCCL), even for one rank
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+        if args.share_gpu:      # RCCL refuses two ranks on one device
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(ge.LIB):

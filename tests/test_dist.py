@@ -268,3 +268,45 @@ def test_all_gather_rows_and_distributional_fit_gloo_world2():
     for r in res:
         assert np.array_equal(r[1], exp[0]) and r[2].tobytes() == exp[1].tobytes() and r[3].tobytes() == exp[2].tobytes()
     assert res[0][4].tobytes() == res[1][4].tobytes()          # the replicas took the same steps
+
+
+def _empty_rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from tetris_mcts_amd import dist as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, d, v = _rows(0)
+    if rank == 1:         # this rank's games have not collected yet: nothing harvested
+        k, d, v = k[:0], d[:0], v[:0]
+    ka, da, va = tdist.all_gather_rows(k, d, v)
+    tk, ts = _tuples(0)
+    if rank == 1:
+        tk, ts = tk[:0], ts[:0]
+    tka, tsa = tdist.all_gather_tuples(tk, ts)
+    # nobody has anything: both calls still return (and nobody hangs in a collective the others skipped)
+    e = tdist.all_gather_rows(k[:0], d[:0], v[:0])
+    q.put((rank, ka.numpy(), da.numpy(), va.numpy(), tka.numpy(), tsa.numpy(), [tuple(x.shape) for x in e]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_with_a_rank_that_has_no_rows_gloo_world2():
+    """Collections are not synchronised over the ranks: a rank with nothing harvested yet takes part in the exchange with zero
+    rows (round-4 advisor: reshape(0, -1) raised on that rank before the collectives and the other ranks hung)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_empty_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    k, d, v = _rows(0)
+    tk, ts = _tuples(0)
+    for r in res:
+        assert np.array_equal(r[1], k.numpy()) and r[2].tobytes() == d.numpy().tobytes() and r[3].tobytes() == v.numpy().tobytes()
+        assert np.array_equal(r[4], tk.numpy()) and r[5].tobytes() == ts.numpy().tobytes()
+        assert r[6] == [(0, 12), (0, 64), (0,)]

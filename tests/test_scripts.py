@@ -84,3 +84,10 @@ def test_committed_bench_line_keeps_the_contract():
     assert d["value"] * d["ms_per_step"] * 1e-3 <= d["config"]["games_per_gpu"] * d["config"]["sims_per_move"]
     assert set(d["other_configs"]) == {"ValueSimLP", "DistValueSim", "Vanilla"} and all("error" not in v or v["error"] is None for v in d["other_configs"].values())
     assert d["steady_state"]["ms_per_step"] < 1.1 * d["ms_per_step"]        # the steady state within 10 % of the headline
+
+
+def test_bench_gpus_n_without_n_devices_says_so():
+    """`python bench.py --gpus N` on a box with fewer than N GPUs ends with a message that names both numbers (it used to die
+    in an assert about --nproc-per-node); a rank count that differs from --gpus is named as well."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs 64 visible GPUs" in r.stderr and "Traceback" not in r.stderr

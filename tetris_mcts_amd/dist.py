@@ -7,6 +7,8 @@ harvests (ValueSim.store_nodes, ValueSim.py:122-159), so every rank can train th
 (train.train_data then splits each batch over the ranks and averages the gradients with one all-reduce per iteration).
 Backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -42,6 +44,15 @@ def all_sum(value, device="cpu", group=None):
     return int(t.item())
 
 
+def _gather_device(t, group=None):
+    """Where a payload lives while it is exchanged: the tensor's own device with RCCL; host memory when the group's backend is
+    gloo and the tensor is on a GPU (gloo's all_gather takes no device tensors - two ranks sharing one GPU in the tests, CPU-only
+    jobs).  The result goes back to the tensor's device."""
+    if t.device.type == "cuda" and dist.get_backend(group) == "gloo":
+        return torch.device("cpu")
+    return t.device
+
+
 def all_gather_tuples(obs_keys, stats, group=None):
     """All-gather variable-length training tuples.
 
@@ -52,7 +63,7 @@ def all_gather_tuples(obs_keys, stats, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return obs_keys, stats
     world = dist.get_world_size(group)       # (a one-rank group still goes through the collective: same code path as N ranks)
-    dev = obs_keys.device
+    home, dev = obs_keys.device, _gather_device(obs_keys, group)
     n = torch.tensor([obs_keys.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
@@ -61,12 +72,13 @@ def all_gather_tuples(obs_keys, stats, group=None):
     if m == 0:
         return obs_keys, stats
     # one fused payload: 12 key words + 4 stat words (bit-cast) per tuple
-    pay = torch.zeros(m, 16, dtype=torch.int32, device=dev)
+    pay = torch.zeros(m, 16, dtype=torch.int32, device=home)
     pay[:obs_keys.shape[0], :12] = obs_keys.to(torch.int32)
     pay[:obs_keys.shape[0], 12:] = stats.contiguous().view(torch.int32)
+    pay = pay.to(dev)
     out = [torch.empty_like(pay) for _ in range(world)]
     dist.all_gather(out, pay, group=group)
-    allp = torch.cat([out[r][:counts[r]] for r in range(world)], dim=0)
+    allp = torch.cat([out[r][:counts[r]] for r in range(world)], dim=0).to(home)
     return allp[:, :12].contiguous(), allp[:, 12:].contiguous().view(torch.float32)
 
 
@@ -78,10 +90,12 @@ def all_gather_rows(*cols, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return cols
     world = dist.get_world_size(group)
-    dev = cols[0].device
+    home, dev = cols[0].device, _gather_device(cols[0], group)
     n_loc = cols[0].shape[0]
-    flat = [c.reshape(n_loc, -1).contiguous().view(torch.int32) for c in cols]
-    widths = [f.shape[1] for f in flat]
+    # explicit widths: a rank that has not harvested yet has 0 rows (collections are not synchronised over the ranks), and
+    # reshape(0, -1) is refused - it must still take part in both collectives, or the others hang
+    widths = [max(1, math.prod(c.shape[1:])) for c in cols]
+    flat = [c.reshape(n_loc, w).contiguous().view(torch.int32) for c, w in zip(cols, widths)]
     n = torch.tensor([n_loc], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
@@ -89,11 +103,12 @@ def all_gather_rows(*cols, group=None):
     m = max(counts)
     if m == 0:
         return cols
-    pay = torch.zeros(m, sum(widths), dtype=torch.int32, device=dev)
+    pay = torch.zeros(m, sum(widths), dtype=torch.int32, device=home)
     pay[:n_loc] = torch.cat(flat, dim=1)
+    pay = pay.to(dev)
     out = [torch.empty_like(pay) for _ in range(world)]
     dist.all_gather(out, pay, group=group)
-    allp = torch.cat([out[r][:counts[r]] for r in range(world)], dim=0)
+    allp = torch.cat([out[r][:counts[r]] for r in range(world)], dim=0).to(home)
     res, off = [], 0
     for c, w in zip(cols, widths):
         res.append(allp[:, off:off + w].contiguous().view(c.dtype).reshape((allp.shape[0],) + tuple(c.shape[1:])))
