@@ -93,6 +93,7 @@ enum {
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
 #define TM_ERR_TRACE 2     /* trace longer than max_trace */
 #define TM_ERR_TABLE 4     /* transposition table full */
+#define TM_ERR_EVAL_LIST 8 /* the dense request list overflowed: the caller did not flip eval_parity between two TM_SIM_FRONT launches */
 
 /* agent numerics (which reference twin is reproduced bit for bit) */
 #define TM_KIND_VALUESIM 0     /* agents/ValueSim.py:76-94      : evaluate the leaf, fp64 carry             */
@@ -167,7 +168,10 @@ typedef struct tm_store {
        g appends to segment g % segs: one device atomic per game and launch, spread over the segments' counters); entry d of
        segment s lives at eval_list[(s + segs * (d / eval_slots)) * eval_slots + d % eval_slots].  Two sets of counters: a launch
        with TM_SIM_FRONT appends under eval_parity and clears the other set, so the CALLER FLIPS eval_parity before every such
-       launch and hands the same value to the evaluator call that follows; tm_move_begin clears both. */
+       launch; the evaluator call that follows reads s->eval_parity from the struct it is handed, so it must be handed THE SAME
+       tm_store value (parity included) as the tm_sim_step before it - not a stale copy.  tm_move_begin clears both sets.  A
+       caller that does not flip lets a segment's counter grow from launch to launch: the append is bounded and the game is
+       flagged TM_ERR_EVAL_LIST.  tm_sim_step / tm_move_begin return hipErrorInvalidValue when eval_list / eval_cnt are NULL. */
     int32_t *eval_list;   /* [G*eval_slots][2] (request slot, observation index) */
     int32_t *eval_cnt;    /* [G][2] entries per segment and parity (segment s of the games of *this at [s][parity]) */
     /* TM_KIND_VALUESIM / TM_KIND_CPPAGENT with TM_SIM_EVAL_NEEDED: the evaluator's output per observation, (v, var, epoch bits, 0);
@@ -241,7 +245,7 @@ int tm_store_slice(const tm_store *s, int first, int n, tm_store *out);
  * not depend on n_sub.  tm_search_run returns when all `sims` simulations of every game are complete (it issues the
  * catch-up launches of games that collected garbage, tm_sims_remaining).  vn_params == NULL: no evaluator launches
  * (TM_KIND_VANILLA).  The evaluator follows the store's kind: the value net (tm_valuenet_forward_requests; vn_scratch:
- * n_games * eval_slots * TM_VALUENET_SCRATCH_MFMA floats, zero-filled) or, for TM_KIND_DIST, the distributional head
+ * n_games * eval_slots * TM_VALUENET_SCRATCH_MFMA floats, no initial contents required) or, for TM_KIND_DIST, the distributional head
  * (tm_distnet_forward_requests; vn_params / vn_prepared = its blobs, vn_scratch: n_games * TM_DISTNET_SCRATCH floats).  ev_every > 0: HIP events
  * around every ev_every-th simulation of sub-batch 0 (on the stream it runs on), read back by tm_search_stats:
  * out = {runs, tree launches, catch-up launches, timed samples, sum tree-kernel ms, sum value-net ms, n_sub}. */

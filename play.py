@@ -41,6 +41,10 @@ def build_parser():
     add('--n_games', default=1, type=int, help='[new] concurrent games on the GPU')
     add('--seed', default=0, type=int, help='[new] environment seed (game g uses seed+g)')
     add('--max_moves', default=0, type=int, help='[new] stop after this many moves (0 = no limit)')
+    add('--train_every', default=0, type=int, help='[new] online mode: look for harvested tuples every k moves (0: every move '
+        'with one game - the reference trains at every collection, ValueSim.py:101-120 - every 10 moves with more)')
+    add('--train_min_tuples', default=0, type=int, help='[new] online mode: fit only once this many fresh tuples are held over '
+        'all ranks (0: 1 with one game, 1024 = one training batch with more)')
     return p
 
 
@@ -109,7 +113,9 @@ def main(argv=None):
         if args.online and not args.benchmark and hasattr(agent, 'train_if_collected'):
             # the reference trains inside remove_nodes(), i.e. at every collection (ValueSim.py:101-120); the batched engine
             # harvests on the device during the move and fits here, right after a move in which a collection harvested
-            agent.train_if_collected()
+            # (a batch of games collects somewhere on nearly every move: it looks every few moves and waits for a batch's worth)
+            agent.train_if_collected(every=args.train_every or (1 if G == 1 else 10),
+                                     min_tuples=args.train_min_tuples or (1 if G == 1 else 1024))
         ended = np.atleast_1d(game.end)
         if ended.any():
             scores, lines = np.atleast_1d(game.score), np.atleast_1d(game.line_clears)

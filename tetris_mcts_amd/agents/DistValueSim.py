@@ -42,6 +42,10 @@ class DistValueSim(TreeAgent):
         if evaluator is None:
             from ..model_distributional import Model_Dist
             self.model = model if model is not None else Model_Dist(atoms=self.atoms)
+            if int(getattr(self.model, "atoms", self.atoms)) != self.atoms:
+                # the head's parameter blob is indexed with the store's atom count (tm_distnet_forward_requests): another
+                # count reads fc_v out of bounds
+                raise ValueError("DistValueSim(atoms=%d) was given a model with %d atoms" % (self.atoms, int(self.model.atoms)))
         else:
             self.model = None
 
@@ -88,11 +92,15 @@ class DistValueSim(TreeAgent):
 
     # ---- online training (DistValueSimOnline.py:143-170): tuples harvested on the device at the collections (tree.hip dist_keep /
     # dist_harvest_store), all-gathered over the ranks, the head fitted on their union with Model_Dist's loss ----
-    def train_if_collected(self, **kwargs):
+    def train_if_collected(self, every=1, min_tuples=1, **kwargs):
+        """as ValueSim.train_if_collected: look on every `every`-th call, fit once the job holds `min_tuples` fresh tuples"""
         from .. import dist as tdist
         if not self.online or self.store is None or self.store.s.replay_cap == 0:
             return None
-        if tdist.all_sum(int(self.store.t["replay_count"].sum().item()), self.store.device) == 0:
+        self._train_calls = getattr(self, "_train_calls", 0) + 1
+        if self._train_calls % max(1, int(every)):
+            return None
+        if tdist.all_sum(int(self.store.t["replay_count"].sum().item()), self.store.device) < max(1, int(min_tuples)):
             return None
         return self.train_nodes(**kwargs)
 

@@ -66,13 +66,20 @@ class ValueSim(TreeAgent):
         np.savez(path, states=state.cpu().numpy(), values=value.cpu().numpy(), variance=variance.cpu().numpy(),
                  weights=visit.cpu().numpy())
 
-    def train_if_collected(self, **kwargs):
-        """train_nodes() if a garbage collection has harvested tuples since the last call (the reference's remove_nodes ->
-        store_nodes -> train_nodes chain, ValueSim.py:101-120, runs at every collection); None otherwise."""
+    def train_if_collected(self, every=1, min_tuples=1, **kwargs):
+        """train_nodes() if garbage collections have harvested tuples since the last fit (the reference's remove_nodes ->
+        store_nodes -> train_nodes chain, ValueSim.py:101-120, runs at every collection of its one game); None otherwise.
+        One game: call it after every move with the defaults and the cadence is the reference's.  A batch of games collects
+        somewhere on nearly every move, and looking costs a device sync and a collective: `every` = look only on every k-th
+        call, `min_tuples` = fit only once the job (all ranks) holds that many fresh tuples (play.py: --train_every,
+        --train_min_tuples)."""
         from .. import dist as tdist
         if not self.online or self.store is None or self.store.s.replay_cap == 0:
             return None
-        if tdist.all_sum(int(self.store.t["replay_count"].sum().item()), self.store.device) == 0:
+        self._train_calls = getattr(self, "_train_calls", 0) + 1
+        if self._train_calls % max(1, int(every)):
+            return None
+        if tdist.all_sum(int(self.store.t["replay_count"].sum().item()), self.store.device) < max(1, int(min_tuples)):
             return None
         return self.train_nodes(**kwargs)
 

@@ -869,7 +869,10 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
             if (post) {
                 const int d = base + __popcll(pm & ((1ull << lane) - 1ull));
                 const int at = (seg + segs * (d / slots)) * slots + d % slots;
-                reinterpret_cast<int2*>(S.eval_list)[at] = make_int2(g * slots + lane, (int)post_obs);
+                // (a segment overflows only if the caller did not flip eval_parity between two launches: the counters then
+                // keep growing.  Never write past the list - the game is flagged instead.)
+                if (at < S.n_games * slots) reinterpret_cast<int2*>(S.eval_list)[at] = make_int2(g * slots + lane, (int)post_obs);
+                else atomicOr(&P.gs()[TM_GS_ERR], TM_ERR_EVAL_LIST);
             }
         }
         if (lane == 0) P.gs()[TM_GS_N_EXPAND] = GSV(gsv, TM_GS_N_EXPAND) + 1;
@@ -2854,6 +2857,7 @@ int tm_tree_remove_nodes(const tm_store* s, const uint8_t* mask, void* stream) {
     return TM_LAUNCH_CHECK();
 }
 int tm_sim_step(const tm_store* s, int flags, void* stream) {
+    if (!s->eval_list || !s->eval_cnt) return (int)hipErrorInvalidValue;      // (a tm_store of an older header: no request list)
     // the launch number (bits 8.. of the kernel's flags): what orders a game's wave and its collector workgroup, which
     // only ever hand over at kernel boundaries.  Any two launches that touch the same game differ in it.
     flags = (flags & 0xFF) | (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
@@ -2875,6 +2879,7 @@ int tm_gc_step(const tm_store* s, void* stream) {
     return TM_LAUNCH_CHECK();
 }
 int tm_move_begin(const tm_store* s, int sims, void* stream) {
+    if (!s->eval_cnt) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_move_begin, dim3((s->n_games + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s, sims);
     return TM_LAUNCH_CHECK();
 }
