@@ -71,7 +71,10 @@ def bytes_per_sim(mean_trace_len, k_eval):
 AGENTS = {"ValueSim": 1, "ValueSimLP": 2, "DistValueSim": 4, "Vanilla": 0}     # -> BASELINE.json configs[i]
 
 
-def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx):
+TRAINED_CHECKPOINT = os.path.join("tetris_mcts_amd", "checkpoints", "value_net_online_r05.pt")     # scripts/gpu_r05_train.sh
+
+
+def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx, checkpoint=None):
     """One agent's windows on this rank's games: `warmup` untimed moves, `steps` timed ones (barrier + synchronize on both
     sides, max over ranks, counters summed over ranks), optionally a second window later in the same games.  Returns the fields
     of a bench line (rank 0; None elsewhere) and the model."""
@@ -102,13 +105,15 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx)
         kw["random_seed"] = 0
     else:
         model = Model_VV(backend=args.backend, seed=0)  # model_vv.Net() under torch.manual_seed(0) (random init)
+        if checkpoint:                                  # ... or a trained one, in the reference's checkpoint format (model/model.py:152-160)
+            model.load(checkpoint, verbose=False)
         kw["model"] = model
     game = Tetris(*env_args, seed=tdist.game_seeds(20260925, G, rank), n_games=G)     # game g of rank r = game r*G + g of the job
     if not is_vanilla:
         kw.update(dict(online=True, min_visits_to_store=10, replay_cap=16384) if args.online else dict(online=False))
     agent = getattr(agents, name)(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=max_nodes,
                                   n_sub=NS, ev_every=EV_EVERY, gc_slice_cycles=args.gc_slice_cycles, gc_spec_nodes=args.gc_spec_nodes,
-                                  **kw)
+                                  gc_cost_units=args.gc_cost_units, gc_collectors=args.gc_collectors, **kw)
     agent.update_root(game)
     torch.cuda.synchronize()
     S = agent.store
@@ -116,7 +121,8 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx)
     py_loop = agent.search_model() is False     # the launch loop runs in Python (an evaluator that is not a HIP net)
     K = S.eval_slots
     NS = agent.n_sub
-    tally = dict(episodes=0, lines=0)
+    tally = dict(episodes=0, lines=0, lines_all=0, game_moves=0, ended_lines=[])
+    prev_lines = np.zeros(G, np.int64)      # every game's line count so far in its episode under way
     gather = dict(ms=0.0, tuples=0, bytes=0, calls=0, checksum_ok=True)
 
     def one_step(timed):
@@ -124,10 +130,18 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx)
         game.play(action)
         agent.update_root(game)   # reads game.end: one small host sync per move, as the reference's loop has
         ended = np.atleast_1d(game.end)
+        cur = np.atleast_1d(game.line_clears).astype(np.int64)       # (the same host copy game.end came from: no extra sync)
+        if timed:
+            # the metric's second half without survivorship bias: lines cleared by ALL games in the window, per 1000 moves
+            tally["lines_all"] += int((cur - prev_lines).sum())
+            tally["game_moves"] += G
+        prev_lines[:] = cur
         if ended.any():
             if timed:
                 tally["episodes"] += int(ended.sum())
-                tally["lines"] += int(np.atleast_1d(game.line_clears)[ended].sum())
+                tally["lines"] += int(cur[ended].sum())
+                tally["ended_lines"] += [int(x) for x in cur[ended]]
+            prev_lines[ended] = 0
             game.reset("ended")
             agent.update_root(game)
         if args.online:
@@ -158,7 +172,7 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx)
         return {k: S.counter(k) for k in CNT}
 
     def measure(n_steps):
-        tally["episodes"], tally["lines"] = 0, 0
+        tally.update(episodes=0, lines=0, lines_all=0, game_moves=0, ended_lines=[])
         torch.cuda.synchronize()
         S.search_stats(NS, EV_EVERY, reset=True)
         if py_loop:
@@ -182,14 +196,17 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx)
         d = {k: c1[k] - c0[k] for k in c0}
         tot = torch.tensor([elapsed, d["N_EXPAND"], d["N_SIMS"], d["TRACE_SUM"], d["N_EVAL"], tally["episodes"], tally["lines"], err,
                             d["N_GC"], d["GC_SLICES"], d["N_DROPPED"], ss.get("catchup_launches", 0.0), d["N_POOL_RESET"],
-                            ss.get("gc_launches", 0.0), d["PREFIX_SUM"], d["N_EVAL_SKIP"], d["N_EVAL_CACHED"]], dtype=torch.float64, device=dev)
+                            ss.get("gc_launches", 0.0), d["PREFIX_SUM"], d["N_EVAL_SKIP"], d["N_EVAL_CACHED"],
+                            tally["lines_all"], tally["game_moves"], float(sum(tally["ended_lines"]) + prev_lines.sum()),
+                            float(len(tally["ended_lines"]) + G), ss.get("catchup_waves", 0.0)], dtype=torch.float64, device=dev)
         if world > 1:
             tmax = tot[:1].clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             tot[0] = tmax[0]
         keys = ("elapsed", "n_exp", "n_sims", "tr_sum", "n_eval", "episodes", "lines", "err", "n_gc", "gc_slices", "dropped",
-                "catchup", "pool_resets", "gc_launches", "prefix_sum", "n_skip", "n_cached")
+                "catchup", "pool_resets", "gc_launches", "prefix_sum", "n_skip", "n_cached", "lines_all", "game_moves",
+                "lines_under_way_sum", "episodes_under_way", "catchup_waves")
         r = dict(zip(keys, [float(x) for x in tot.cpu()]))
         r["ss"], r["steps"] = ss, n_steps
         return r
@@ -245,6 +262,9 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx)
         return {"collections": int(r["n_gc"]), "collector_launches_x_games": int(r["gc_slices"]),
                 "launches_per_collection": (r["gc_slices"] / r["n_gc"]) if r["n_gc"] else None,
                 "catchup_launches": int(r["catchup"]), "catchup_launches_per_move": r["catchup"] / r["steps"] / world,
+                # a catch-up launch runs over the games that owe only (tm_store::game_list): their simulation waves, in units of a
+                # full launch's (the evaluator draws from the dense request list and shrinks with them)
+                "catchup_full_launch_equivalents_per_move": r["catchup_waves"] / float(G) / r["steps"] / world,
                 "collector_only_launches": int(r["gc_launches"]), "dropped_tuples": int(r["dropped"]),
                 "trees_restarted_pool_outgrown": int(r["pool_resets"])}
 
@@ -270,11 +290,13 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx)
         "config": {
             "workload": "%d games/GPU x %d sims/move, %s %s (BASELINE configs[%d]); Tetris 20x10 app=1 guideline scoring 7-bag; "
                         "node pool %d/game%s" % (G, sims, name, what, AGENTS[name], max_nodes,
-                                                 "" if is_vanilla else "; network random init under manual_seed(0)"),
+                                                 "" if is_vanilla else ("; network = checkpoint %s" % os.path.basename(checkpoint)) if checkpoint
+                                                 else "; network random init under manual_seed(0)"),
             "workload_key": workload_key,
             "games_per_gpu": G, "sims_per_move": sims, "agent": name, "max_nodes": max_nodes,
             "valuenet_backend": None if is_vanilla else args.backend, "sub_batches": NS, "online": bool(args.online),
-            "gc_slice_cycles": args.gc_slice_cycles, "gc_spec_nodes": args.gc_spec_nodes,
+            "gc_slice_cycles": args.gc_slice_cycles, "gc_spec_nodes": args.gc_spec_nodes, "gc_cost_units": args.gc_cost_units, "gc_collectors": args.gc_collectors,
+            "checkpoint": checkpoint and os.path.relpath(checkpoint, ROOT),
         },
         "sims_per_sec": n_sims / elapsed,
         "child_steps_per_sec": 7.0 * n_exp / elapsed,
@@ -285,6 +307,8 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx)
         "walk_levels_taken_over_from_the_previous_walk": head["prefix_sum"] / max(head["tr_sum"], 1.0),
         "episodes_finished": int(head["episodes"]),
         "lines_cleared_per_episode": (head["lines"] / head["episodes"]) if head["episodes"] else None,
+        "lines_per_1000_moves": 1000.0 * head["lines_all"] / max(head["game_moves"], 1.0),
+        "mean_lines_all_episodes_under_way": head["lines_under_way_sum"] / max(head["episodes_under_way"], 1.0),
         "lines_note": None if head["episodes"] else "no episode ends inside the timed window (random-init network, moves %d-%d "
                       "of every game); the learning curve (lines cleared per episode vs training round) is "
                       "scripts/selfplay_online.py -> profiles/*_online_learning.jsonl" % (warmup + 1, warmup + steps),
@@ -306,6 +330,8 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx)
             "mean_trace_len": steady["tr_sum"] / max(steady["n_sims"], 1.0),
             "episodes_finished": int(steady["episodes"]),
             "lines_cleared_per_episode": (steady["lines"] / steady["episodes"]) if steady["episodes"] else None,
+            "lines_per_1000_moves": 1000.0 * steady["lines_all"] / max(steady["game_moves"], 1.0),
+            "mean_lines_all_episodes_under_way": steady["lines_under_way_sum"] / max(steady["episodes_under_way"], 1.0),
             "requests": request_block(steady),
             "error_games": int(steady["err"]), "gc": gc_block(steady),
             "tree_kernel_ms": kf["tree_ms"] if kf else None, "value_net_ms": kf["nn_ms"] if kf else None,
@@ -362,7 +388,8 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx)
 def compact(line):
     """a secondary config's line inside the headline's: the figures, not the prose"""
     keep = ("value", "unit", "steps", "warmup", "ms_per_step", "sims_per_sec", "evaluated_states_per_sec", "requests", "mean_trace_len",
-            "episodes_finished", "lines_cleared_per_episode", "error_games", "store_gib_per_gpu", "cpu_baseline")
+            "max_trace_len", "episodes_finished", "lines_cleared_per_episode", "lines_per_1000_moves", "mean_lines_all_episodes_under_way",
+            "error_games", "store_gib_per_gpu", "cpu_baseline", "steady_state", "gc")
     out = {k: line[k] for k in keep if k in line}
     out["workload"] = line["config"]["workload"]
     for rk in ("roofline", "roofline_other"):
@@ -390,6 +417,9 @@ def main():
     ap.add_argument("--gc-slice-cycles", type=int, default=150000)
     ap.add_argument("--gc-spec-nodes", type=int, default=None,
                     help="free nodes below which a game's tree is marked while it goes on simulating (default: the store's)")
+    ap.add_argument("--gc-cost-units", type=int, default=0, help="bounded collection steps a launch takes on, in cost units (0: the store's default)")
+    ap.add_argument("--gc-collectors", type=int, default=0, help="collector workgroups per launch (0: the store's default, 128)")
+    ap.add_argument("--checkpoint", default=None, help="value-net checkpoint for the measured agent (default: random init under manual_seed(0))")
     ap.add_argument("--online", action="store_true", help="harvest training tuples at GC and all-gather them every move")
     ap.add_argument("--steady-warmup", type=int, default=75, help="the steady-state window starts after this many moves")
     ap.add_argument("--steady-steps", type=int, default=20, help="moves of the second, steady-state window (0: none)")
@@ -449,10 +479,11 @@ def main():
     ctx = dict(rank=rank, world=world)
     sims = args.sims if args.sims is not None else (100 if args.agent == "Vanilla" else 500)
     args.sims = sims
-    out, model = run_agent(args, args.agent, sims, args.warmup, args.steps, args.steady_warmup, args.steady_steps, ctx)
+    out, model = run_agent(args, args.agent, sims, args.warmup, args.steps, args.steady_warmup, args.steady_steps, ctx,
+                           checkpoint=args.checkpoint and os.path.abspath(args.checkpoint))
     others = {}
     want_others = args.others == "all" or (args.others == "auto" and world == 1 and args.agent == "ValueSim" and not args.online
-                                           and args.backend == "hip" and args.split == 1)
+                                           and args.backend == "hip" and args.split == 1 and not args.checkpoint)
     if want_others:
         # the other configurations of BASELINE.json, short windows, so that the driver's one command line shows them all
         for name, osims, w, k in (("ValueSimLP", 500, 5, 20), ("DistValueSim", 1000, 2, 5), ("Vanilla", 100, 5, 20)):
@@ -466,7 +497,40 @@ def main():
             except Exception as e:          # a secondary line never costs the headline
                 import traceback
                 others[name] = {"error": repr(e), "trace": traceback.format_exc()[-400:]}
+    trained = None
+    ck = os.path.join(ROOT, TRAINED_CHECKPOINT)
+    if want_others and os.path.isfile(ck):
+        # the metric's second half: the headline's own windows (moves 6-25 and 76-95 of 4096 games x 500 simulations) under a value
+        # net that this engine's online self-play trained (scripts/gpu_r05_train.sh; profiles/r05_online_learning*.jsonl is its
+        # learning curve) - throughput under narrower, deeper-valued trees, and the lines the search clears with it
+        try:
+            line, tmodel = run_agent(args, "ValueSim", sims, args.warmup, args.steps, args.steady_warmup, args.steady_steps, ctx, checkpoint=ck)
+            if rank == 0:
+                import hashlib
+                trained = compact(line)
+                trained["checkpoint"] = {"file": TRAINED_CHECKPOINT, "sha256_16": hashlib.sha256(open(ck, "rb").read()).hexdigest()[:16],
+                                         "format": "torch.save({'model_state_dict', 'optimizer_state_dict'}) as model/model.py:152-160 of the reference",
+                                         "trained_by": "scripts/selfplay_online.py (ValueSimLP, 512 games x 200 sims, online TD fits every 50 moves), one MI355X"}
+            del tmodel
+        except Exception as e:
+            import traceback
+            trained = {"error": repr(e), "trace": traceback.format_exc()[-400:]}
     if rank == 0:
+        if trained is not None:
+            out["trained_net"] = trained
+        # the other lines' headline numbers as scalars of the line itself (a reader that keeps only top-level scalars keeps them)
+        if "steady_state" in out:
+            out["steady_value"], out["steady_ms_per_step"] = out["steady_state"]["value"], out["steady_state"]["ms_per_step"]
+        for key, name in (("lp", "ValueSimLP"), ("dist", "DistValueSim"), ("vanilla", "Vanilla")):
+            if "value" in others.get(name, {}):
+                out[key + "_value"], out[key + "_ms_per_step"] = others[name]["value"], others[name]["ms_per_step"]
+        if trained and "value" in trained:
+            out["trained_value"], out["trained_ms_per_step"] = trained["value"], trained["ms_per_step"]
+            out["trained_mean_trace_len"] = trained["mean_trace_len"]
+            out["trained_lines_per_1000_moves"] = trained["lines_per_1000_moves"]
+            if "steady_state" in trained:
+                out["trained_steady_lines_per_1000_moves"] = trained["steady_state"]["lines_per_1000_moves"]
+                out["trained_steady_mean_lines_all_episodes_under_way"] = trained["steady_state"]["mean_lines_all_episodes_under_way"]
         if others:
             out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:

@@ -87,13 +87,17 @@ enum {
     TM_GS_LEAF_OBS,      /* the pending leaf's observation (TM_SIM_EVAL_NEEDED: where the backup files the evaluator's output) */
     TM_GS_N_EVAL_SKIP,   /* leaf-parallel kinds: unique children of expanded leaves whose evaluation the backup would discard
                             (observation already visited / finished) - not posted under TM_SIM_EVAL_NEEDED, counted always */
-    TM_GS_N_EVAL_CACHED  /* TM_KIND_VALUESIM / TM_KIND_CPPAGENT under TM_SIM_EVAL_NEEDED: leaves answered from obs_eval */
+    TM_GS_N_EVAL_CACHED, /* TM_KIND_VALUESIM / TM_KIND_CPPAGENT under TM_SIM_EVAL_NEEDED: leaves answered from obs_eval */
+    TM_GS_GC_NGC         /* collector workgroups of the launch that began the collection under way (its shares are cut for that many) */
 };
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
 #define TM_ERR_TRACE 2     /* trace longer than max_trace */
 #define TM_ERR_TABLE 4     /* transposition table full */
 #define TM_ERR_EVAL_LIST 8 /* the dense request list overflowed: the caller did not flip eval_parity between two TM_SIM_FRONT launches */
+#define TM_ERR_GC_GRID 16  /* a collection under way was met by a launch with another number of collector workgroups than the launch
+                              that began it (launches over another range of games: a sub-batch, the full store): the shares and the
+                              arrival count would not add up, so the collection is not touched and the game is flagged */
 
 /* agent numerics (which reference twin is reproduced bit for bit) */
 #define TM_KIND_VALUESIM 0     /* agents/ValueSim.py:76-94      : evaluate the leaf, fp64 carry             */
@@ -183,6 +187,16 @@ typedef struct tm_store {
        agents/DistValueSimOnline.py:116-141: a freed node with >= min_visits_to_store visits whose seven children have all been
        visited; replay_obs = its packed observation, replay_stat = (0, 0, visits, 0)) */
     float *replay_dist;   /* [G][replay_cap][TM_DIST_ROW] */
+    /* a launch over SOME of the games (the catch-up launches at the end of a move: a handful of games that spent launches
+       collecting garbage still owe simulations): simulation wave i of tm_sim_step takes game game_list[i], i < n_listed; the
+       collector workgroups look after all n_games as always.  NULL: every game (wave i = game i).  Filled by tm_sims_owing. */
+    const int32_t *game_list;
+    int32_t n_listed;
+    int32_t gc_cost_units; /* cost units of bounded collection steps (init / count 1, write 2, re-insertion of nodes / observations 5
+                              each: about 5 microseconds a unit) the collector workgroups of one tm_sim_step launch take on; 0: the
+                              default (12).  More units serve more collections per launch and make the launch longer. */
+    int32_t gc_collectors; /* collector workgroups per tm_sim_step launch (half for the bounded steps, half for the marking); 0: the
+                              default (128), at most 128.  A collection must be continued by launches with the same number. */
 } tm_store;
 #define TM_EVAL_SEGS(n_games) ((n_games) < 64 ? (n_games) : 64)
 
@@ -220,6 +234,9 @@ int tm_tree_remove_nodes(const tm_store *s, const uint8_t *mask, void *stream); 
  * collection instead (s->gc_slice_cycles), so `sims` launches + 1 are enough unless a game collected in this move. */
 int tm_move_begin(const tm_store *s, int sims, void *stream);
 int tm_sims_remaining(const tm_store *s, int32_t *out /* device int[2]: max over games of launches still needed; games whose collection is under way */, void *stream);
+/* the same, and WHICH games still need launches: out[2] = their number, list[0 .. out[2]) = their indices (any order; list:
+ * device int32[n_games]) - what a caller puts into tm_store::game_list / n_listed for the launches that follow */
+int tm_sims_owing(const tm_store *s, int32_t *out /* device int[3] */, int32_t *list, void *stream);
 /* one step of every garbage collection under way (the collector workgroups of tm_sim_step alone, no simulation): what the
  * driver launches instead of whole simulation launches while it waits for collections at the end of a move */
 int tm_gc_step(const tm_store *s, void *stream);

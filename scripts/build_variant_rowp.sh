@@ -9,7 +9,7 @@ NAME=${1:-rowp}; KB=${2:-84}; BL=${3:-256}
 cd "$(dirname "$0")/.."
 mkdir -p build_variants /tmp/tmv_$NAME
 sed -e "s/const int lds = 4 \* WAVE_LDS \* (int)sizeof(float);/const int lds = $KB * 1024;/" \
-    -e "s/if (blocks > 256 \* TM_CONV_WG_PER_CU) blocks = 256 \* TM_CONV_WG_PER_CU;/if (blocks > $BL) blocks = $BL;/" \
+    -e "s/if (blocks > 256 \* CONV_WG_PER_CU) blocks = 256 \* CONV_WG_PER_CU;/if (blocks > $BL) blocks = $BL;/" \
     tetris_mcts_amd/csrc/valuenet.hip > /tmp/tmv_$NAME/valuenet.hip
 cp tetris_mcts_amd/csrc/*.inc /tmp/tmv_$NAME/
 grep -c "const int lds = $KB \* 1024;\|if (blocks > $BL) blocks = $BL;" /tmp/tmv_$NAME/valuenet.hip

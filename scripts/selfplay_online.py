@@ -27,6 +27,8 @@ ap.add_argument("--train-every", type=int, default=100, help="moves between trai
 ap.add_argument("--train-iters", type=int, default=3000)
 ap.add_argument("--min-visits", type=int, default=None, help="min_visits_to_store (default: the agent's)")
 ap.add_argument("--out", default="gpurun_out/online_learning.jsonl")
+ap.add_argument("--save", default=None, help="checkpoint file (the reference's format, model/model.py:152-160), written every --save-every rounds and at the end")
+ap.add_argument("--save-every", type=int, default=10)
 args = ap.parse_args()
 
 M.EXP_PATH = "/tmp/tm_ckpt/"
@@ -94,4 +96,9 @@ while time.time() - t0 < args.minutes * 60:
         print(rec, flush=True)
         ep_lines, ep_scores, ep_len = [], [], []
         lines_round, moves_round = 0, 0
+        if args.save and rounds % args.save_every == 0:
+            model.save(filename=args.save, verbose=False)
 log.close()
+if args.save:
+    model.save(filename=args.save, verbose=False)
+    print("checkpoint written to", args.save, flush=True)

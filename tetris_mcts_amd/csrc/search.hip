@@ -29,8 +29,10 @@ struct tm_search {
     std::vector<hipStream_t> streams;
     hipEvent_t ev_start = nullptr;
     std::vector<hipEvent_t> ev_done;
-    int32_t* rem_dev = nullptr;
+    int32_t* rem_dev = nullptr;      // per sub-batch: launches still needed, collections under way, games that owe launches
     int32_t* rem_host = nullptr;
+    int32_t* owing_dev = nullptr;    // [n_games] the games that owe launches, per sub-batch at its first game (tm_sims_owing)
+    long long extra_waves = 0;       // simulation waves of the catch-up launches (a full launch has n_games of them)
     // HIP events around the regular launches of a move (sub-batch 0's stream): the time the per-kernel figures must add up to
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
     double loop_ms = 0;
@@ -132,9 +134,11 @@ int tm_search_create(tm_search** out, const tm_store* s, int n_sub, int ev_every
         if (e != hipSuccess) return fail((int)e);
         h->ev_done.push_back(d);
     }
-    e = hipMalloc(&h->rem_dev, sizeof(int32_t) * 2 * n_sub);
+    e = hipMalloc(&h->rem_dev, sizeof(int32_t) * 3 * n_sub);
     if (e != hipSuccess) return fail((int)e);
-    e = hipHostMalloc(&h->rem_host, sizeof(int32_t) * 2 * n_sub, hipHostMallocDefault);
+    e = hipHostMalloc(&h->rem_host, sizeof(int32_t) * 3 * n_sub, hipHostMallocDefault);
+    if (e != hipSuccess) return fail((int)e);
+    e = hipMalloc(&h->owing_dev, sizeof(int32_t) * (size_t)(G > 0 ? G : 1));
     if (e != hipSuccess) return fail((int)e);
     *out = h;
     return 0;
@@ -149,6 +153,7 @@ void tm_search_destroy(tm_search* h) {
     if (h->ev_loop0) (void)hipEventDestroy(h->ev_loop0);
     if (h->ev_loop1) (void)hipEventDestroy(h->ev_loop1);
     if (h->rem_dev) (void)hipFree(h->rem_dev);
+    if (h->owing_dev) (void)hipFree(h->owing_dev);
     if (h->rem_host) (void)hipHostFree(h->rem_host);
     delete h;
 }
@@ -166,12 +171,18 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
         TM_TRY(hipEventRecord(h->ev_start, caller));
         for (int k = 0; k < K; ++k) TM_TRY(hipStreamWaitEvent(st[k], h->ev_start, 0));
     }
-    auto step = [&](int k, int extra = 0) -> int {
+    // `owing` > 0: a launch over the games of tm_sims_owing's list only (tm_store::game_list)
+    auto step = [&](int k, int owing = 0) -> int {
         if (h->sub[k].n_games == 0) return 0;
         h->launches += 1;
         h->sub[k].eval_parity ^= 1;      // the dense request list: every launch appends under the other parity (tm_store::eval_list)
+        h->sub[k].game_list = owing > 0 ? h->owing_dev + h->first[k] : nullptr;
+        h->sub[k].n_listed = owing;
         // the evaluator is the built-in net, a function of the observation: only the requests whose outputs the backup uses
-        return tm_sim_step(&h->sub[k], TM_SIM_BACKUP | TM_SIM_FRONT | (vn_params ? TM_SIM_EVAL_NEEDED : 0) | extra, st[k]);
+        const int e = tm_sim_step(&h->sub[k], TM_SIM_BACKUP | TM_SIM_FRONT | (vn_params ? TM_SIM_EVAL_NEEDED : 0), st[k]);
+        h->sub[k].game_list = nullptr;
+        h->sub[k].n_listed = 0;
+        return e;
     };
     auto nn = [&](int k) -> int {
         if (!vn_params || h->sub[k].n_games == 0) return 0;
@@ -207,29 +218,34 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
     TM_TRY(hipEventRecord(h->ev_loop1, st[0]));
     // catch-up: games that spent launches collecting garbage still owe simulations.  Collections still under way are
     // finished first, by collector-only launches (tm_gc_step: a step of every collection each, no simulation, no evaluator).
-    for (;;) {
+    // The catch-up launches run over the games that owe only (a handful of 4096: tm_sims_owing lists them, tm_store::game_list),
+    // so their tree kernel is a few workgroups beside the collectors and the evaluator draws a few requests from the dense list.
+    for (long long rounds = 0;; ++rounds) {
+        // (every round finishes simulations or steps of collections; a move that needs this many is not making progress)
+        if (rounds > 64LL * sims + 100000) return (int)hipErrorLaunchFailure;
         for (int k = 0; k < K; ++k) {
-            h->rem_host[2 * k] = h->rem_host[2 * k + 1] = 0;
+            h->rem_host[3 * k] = h->rem_host[3 * k + 1] = h->rem_host[3 * k + 2] = 0;
             if (h->sub[k].n_games == 0) continue;
-            TM_TRY(tm_sims_remaining(&h->sub[k], h->rem_dev + 2 * k, st[k]));
-            TM_TRY(hipMemcpyAsync(h->rem_host + 2 * k, h->rem_dev + 2 * k, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st[k]));
+            TM_TRY(tm_sims_owing(&h->sub[k], h->rem_dev + 3 * k, h->owing_dev + h->first[k], st[k]));
+            TM_TRY(hipMemcpyAsync(h->rem_host + 3 * k, h->rem_dev + 3 * k, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st[k]));
         }
         for (int k = 0; k < K; ++k) TM_TRY(hipStreamSynchronize(st[k]));
         int r = 0, collecting = 0;
-        for (int k = 0; k < K; ++k) { r = h->rem_host[2 * k] > r ? h->rem_host[2 * k] : r; collecting += h->rem_host[2 * k + 1]; }
+        for (int k = 0; k < K; ++k) { r = h->rem_host[3 * k] > r ? h->rem_host[3 * k] : r; collecting += h->rem_host[3 * k + 1]; }
         if (r == 0) break;
         if (collecting > 0) {
             for (int i = 0; i < 6; ++i)
                 for (int k = 0; k < K; ++k)
-                    if (h->rem_host[2 * k + 1] > 0) { TM_TRY(tm_gc_step(&h->sub[k], st[k])); h->gc_launches += 1; }
+                    if (h->rem_host[3 * k + 1] > 0) { TM_TRY(tm_gc_step(&h->sub[k], st[k])); h->gc_launches += 1; }
             continue;
         }
         for (int i = 0; i < r; ++i)
             for (int k = 0; k < K; ++k)
-                if (h->rem_host[2 * k] > i) {
+                if (h->rem_host[3 * k] > i) {
                     TM_TRY(nn(k));
-                    TM_TRY(step(k));
+                    TM_TRY(step(k, h->rem_host[3 * k + 2]));
                     h->extra_launches += 1;
+                    h->extra_waves += h->rem_host[3 * k + 2];
                 }
     }
     for (int j = 0; j + 2 < h->ev_used; j += 3) {
@@ -257,19 +273,19 @@ int tm_search_set_epoch(tm_search* h, int epoch) {
     return 0;
 }
 
-// out[0..9] = runs, tree-kernel launches, catch-up launches, timed samples, sum of tree-kernel ms, sum of value-net ms,
+// out[0..10] = runs, tree-kernel launches, catch-up launches, timed samples, sum of tree-kernel ms, sum of value-net ms,
 // sub-batches, collector-only launches, sum of the regular launch loops' ms (HIP events around sims x (value net, tree
-// kernel) of sub-batch 0's stream), simulations in those loops; the per-kernel sums are over the timed samples (sub-batch
-// 0, every ev_every-th simulation)
+// kernel) of sub-batch 0's stream), simulations in those loops, simulation waves of the catch-up launches (each runs over the
+// games that owe only); the per-kernel sums are over the timed samples (sub-batch 0, every ev_every-th simulation)
 int tm_search_stats(tm_search* h, double* out, int n, int reset) {
-    double v[10] = {(double)h->n_runs, (double)h->launches, (double)h->extra_launches, (double)h->n_timed, h->tree_ms,
-                    h->nn_ms, (double)h->n_sub, (double)h->gc_launches, h->loop_ms, (double)h->loop_sims};
-    for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+    double v[11] = {(double)h->n_runs, (double)h->launches, (double)h->extra_launches, (double)h->n_timed, h->tree_ms,
+                    h->nn_ms, (double)h->n_sub, (double)h->gc_launches, h->loop_ms, (double)h->loop_sims, (double)h->extra_waves};
+    for (int i = 0; i < n && i < 11; ++i) out[i] = v[i];
     if (reset) {
         h->tree_ms = h->nn_ms = h->loop_ms = 0;
-        h->n_timed = h->n_runs = h->extra_launches = h->launches = h->gc_launches = h->loop_sims = 0;
+        h->n_timed = h->n_runs = h->extra_launches = h->launches = h->gc_launches = h->loop_sims = h->extra_waves = 0;
     }
-    return 10;
+    return 11;
 }
 
 }  // extern "C"

@@ -281,6 +281,7 @@ constexpr int GC_REQ = 1, GC_DONE = 7;   // phase word: (launch << 4) | GC_REQ r
 // business), GC_SPEC_MARK (GC_REQ_SPEC) or a pending GC_SPEC_REQ (GC_REQ_OVER).
 constexpr int GC_SPEC_REQ = 8, GC_SPEC_MARK = 9, GC_REQ_SPEC = 10, GC_REQ_OVER = 12;
 constexpr int GC_IDLE = 11;        // (a step, not a phase: a speculative marking that has nothing to do in this launch)
+constexpr int GC_FOREIGN = 13;     // (a step, not a phase: a collection that launches with another number of collectors began - not touched)
 
 
 // `gsv`: the wave's snapshot of the game's control block (word i in lane i), valid when nothing in this launch has changed
@@ -1445,11 +1446,19 @@ __device__ __forceinline__ void wave_dist_front(const tm_store& S, const GP& P, 
 // carries the launch number for that: a request is (launch << 4) | 1 and is picked up by the collectors of LATER
 // launches; a finished collection leaves (launch << 4) | 7 and the game's wave resumes in a LATER launch.
 // ---------------------------------------------------------------------------------------------------
-constexpr int GC_BLOCKS_MAX = 64;   // collector workgroups of a k_sim_step launch: half for the bounded steps, half for the marking (measured: with a
-                                    // quarter for the marking a collection takes 35 launches instead of 23)
-__host__ __device__ inline int gc_blocks(int n_games) {
-    const int sim_blocks = (n_games + WPB - 1) / WPB;
-    return sim_blocks < GC_BLOCKS_MAX ? sim_blocks : GC_BLOCKS_MAX;
+// Collector workgroups of a k_sim_step launch: half for the bounded steps, half for the marking (measured, r03: with a quarter for
+// the marking a collection takes 35 launches instead of 23).  128 since r05: under a TRAINED value net every simulation expands a
+// node, the pools fill twice as fast and the trees that survive a move are larger - 64 collectors kept a game waiting 78 launches
+// per collection (161 ms per move in the steady state), 128 keep it 17 (103 ms); 192 or another split: no further gain
+// (profiles/r05_gc_sweep_trained_net.json).  Under the random-init net of the headline window 128 cost 0.5-2 %.
+constexpr int GC_BLOCKS_DEFAULT = 128;
+constexpr int GC_BLOCKS_MAX = 128;      // (tm_store::gc_collectors; the bounded half keeps three counts per workgroup in TM_GC_PART_DW words)
+static_assert(3 * (GC_BLOCKS_MAX / 2) <= TM_GC_PART_DW, "three counts per bounded workgroup (half of the collectors)");
+__host__ __device__ inline int gc_blocks(const tm_store& S) {
+    const int sim_blocks = (S.n_games + WPB - 1) / WPB;
+    int want = S.gc_collectors > 0 ? S.gc_collectors : GC_BLOCKS_DEFAULT;
+    if (want > GC_BLOCKS_MAX) want = GC_BLOCKS_MAX;
+    return sim_blocks < want ? sim_blocks : want;
 }
 
 template <int T> struct Grp {
@@ -1876,6 +1885,7 @@ struct GcLds {
     short list_part[GC_LIST_MAX], list_parts[GC_LIST_MAX], list_share[GC_LIST_MAX];     // this workgroup's share (part of parts; parts 0: not in this launch)
     short order[GC_LIST_MAX]; int n_order;              // the games this workgroup works on, in order
     int age[GC_LIST_WAIT]; short by_age[GC_LIST_WAIT];  // the waiting games: launches since the request, and sorted by that
+    int hist[256];                                      // more than GC_LIST_WAIT games waiting: how many have waited how long
     int ring_start[GC_RING], ring_cnt[GC_RING];
 };
 
@@ -1890,7 +1900,6 @@ __device__ __forceinline__ bool gc_arrive(int32_t* gs, int n_gc, bool leftover, 
     return true;
 }
 
-static_assert(3 * GC_BLOCKS_MAX <= TM_GC_PART_DW, "three counts per bounded workgroup");
 __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags, int n_gc, GcLds& M) {
     constexpr int T = 64 * WPB;
     typedef Grp<T> G_;
@@ -1907,49 +1916,105 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
     // are waiting for their collection (at most GC_LIST_WAIT), then the speculative markings ----
     // thread t looks at a contiguous run of games (all its loads in flight together, one prefix sum for the whole list)
     int n_wait = 0, n_spec = 0;
-    {
-        constexpr int RUN = 16;
+    constexpr int RUN = 16;
+    // (a phase word that the game's wave replaces in the middle of a launch reads as what it replaced, see GC_REQ_OVER)
+    auto classify = [&](int& word) -> int {       // 0: waiting for its collection, 1: speculative marking, -1: neither
+        const int ph = word & 15;
+        const bool now = (word >> 4) == seq;
+        if (ph >= GCP_MARK && ph <= GCP_OBS) return 0;
+        if (ph == GC_REQ) return now ? -1 : 0;
+        if (ph == GC_SPEC_REQ) return now ? -1 : 1;
+        if (ph == GC_SPEC_MARK) return 1;
+        if (ph == GC_REQ_SPEC) { if (now) { word = GC_SPEC_MARK; return 1; } return 0; }
+        if (ph == GC_REQ_OVER) {
+            // (the compare-and-swap to GC_SPEC_MARK at the end of the step fails whichever word the last arriver expects)
+            if (now) { word = (word & ~15) | GC_SPEC_REQ; return 1; }
+            return 0;
+        }
+        return -1;
+    };
+    int n_wait_all = 0;
+    for (int base = 0; base < S.n_games; base += T * RUN) {
+        int word[RUN];
+#pragma unroll
+        for (int r = 0; r < RUN; ++r) {
+            const int g = base + tid * RUN + r;
+            word[r] = g < S.n_games ? S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_PHASE] : 0;
+        }
+        uint32_t todo_w = 0, todo_s = 0;
+#pragma unroll
+        for (int r = 0; r < RUN; ++r) {
+            const int cls = classify(word[r]);
+            if (cls == 0) todo_w |= 1u << r;
+            if (cls == 1) todo_s |= 1u << r;
+        }
+        int total_w, total_s;
+        int pos_w = n_wait_all + G_::exscan(__popc(todo_w), tid, sm, total_w);
+        int pos_s = GC_LIST_WAIT + n_spec + G_::exscan(__popc(todo_s), tid, sm, total_s);
+        for (uint32_t bits = todo_w; bits; bits &= bits - 1) {
+            const int r = __ffs(bits) - 1;
+            if (pos_w < GC_LIST_WAIT) { M.list_g[pos_w] = base + tid * RUN + r; M.list_ph[pos_w] = word[r]; }
+            pos_w += 1;
+        }
+        for (uint32_t bits = todo_s; bits; bits &= bits - 1) {
+            const int r = __ffs(bits) - 1;
+            if (pos_s < GC_LIST_MAX) { M.list_g[pos_s] = base + tid * RUN + r; M.list_ph[pos_s] = word[r]; }
+            pos_s += 1;
+        }
+        n_wait_all += total_w;
+        n_spec = min(GC_LIST_MAX - GC_LIST_WAIT, n_spec + total_s);
+    }
+    n_wait = min(GC_LIST_WAIT, n_wait_all);
+    if (n_wait_all > GC_LIST_WAIT) {
+        // More games wait than a launch looks after: the ones that have waited LONGEST get the places (in game-index order the
+        // high-numbered games of a big batch waited for all the others, and a move's catch-up is as long as its slowest game).
+        // A histogram of the waiting times (launches since the request, capped) gives the cut-off; the games beyond it, and of
+        // those at it the first in index order, are taken.  Every workgroup reads the same words: the same list everywhere.
+        __syncthreads();
+        M.hist[tid] = 0;
+        __syncthreads();
+        auto age_of = [&](int g) { return min(255, (seq - S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_REQ_AT]) & 0x7FFFF); };
+        for (int base = 0; base < S.n_games; base += T * RUN) {
+#pragma unroll
+            for (int r = 0; r < RUN; ++r) {
+                const int g = base + tid * RUN + r;
+                int word = g < S.n_games ? S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_PHASE] : 0;
+                if (classify(word) == 0) atomicAdd(&M.hist[age_of(g)], 1);
+            }
+        }
+        __syncthreads();
+        int cut = 255, older = 0;              // older = games that have waited longer than `cut` launches (< GC_LIST_WAIT of them)
+        for (; cut > 0 && older + M.hist[cut] < GC_LIST_WAIT; --cut) older += M.hist[cut];
+        __syncthreads();
+        int n_old = 0, n_eq = 0;
         for (int base = 0; base < S.n_games; base += T * RUN) {
             int word[RUN];
+            uint32_t m_old = 0, m_eq = 0;
 #pragma unroll
             for (int r = 0; r < RUN; ++r) {
                 const int g = base + tid * RUN + r;
                 word[r] = g < S.n_games ? S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_PHASE] : 0;
-            }
-            uint32_t todo_w = 0, todo_s = 0;
-#pragma unroll
-            for (int r = 0; r < RUN; ++r) {
-                // (a phase word that the game's wave replaces in the middle of a launch reads as what it replaced, see GC_REQ_OVER)
-                const int ph = word[r] & 15;
-                const bool now = (word[r] >> 4) == seq;
-                int cls = -1;                           // 0: waiting for its collection, 1: speculative marking
-                if (ph >= GCP_MARK && ph <= GCP_OBS) cls = 0;
-                else if (ph == GC_REQ) cls = now ? -1 : 0;
-                else if (ph == GC_SPEC_REQ) cls = now ? -1 : 1;
-                else if (ph == GC_SPEC_MARK) cls = 1;
-                else if (ph == GC_REQ_SPEC) { if (now) { word[r] = GC_SPEC_MARK; cls = 1; } else cls = 0; }
-                else if (ph == GC_REQ_OVER) {
-                    // (the compare-and-swap to GC_SPEC_MARK at the end of the step fails whichever word the last arriver expects)
-                    if (now) { word[r] = (word[r] & ~15) | GC_SPEC_REQ; cls = 1; } else cls = 0;
+                if (classify(word[r]) == 0) {
+                    const int a = age_of(g);
+                    if (a > cut) m_old |= 1u << r;
+                    else if (a == cut) m_eq |= 1u << r;
                 }
-                if (cls == 0) todo_w |= 1u << r;
-                if (cls == 1) todo_s |= 1u << r;
             }
-            int total_w, total_s;
-            int pos_w = n_wait + G_::exscan(__popc(todo_w), tid, sm, total_w);
-            int pos_s = GC_LIST_WAIT + n_spec + G_::exscan(__popc(todo_s), tid, sm, total_s);
-            for (uint32_t bits = todo_w; bits; bits &= bits - 1) {
+            int t_old, t_eq;
+            int p_old = n_old + G_::exscan(__popc(m_old), tid, sm, t_old);
+            int p_eq = older + n_eq + G_::exscan(__popc(m_eq), tid, sm, t_eq);
+            for (uint32_t bits = m_old; bits; bits &= bits - 1) {
                 const int r = __ffs(bits) - 1;
-                if (pos_w < GC_LIST_WAIT) { M.list_g[pos_w] = base + tid * RUN + r; M.list_ph[pos_w] = word[r]; }
-                pos_w += 1;
+                M.list_g[p_old] = base + tid * RUN + r; M.list_ph[p_old] = word[r];
+                p_old += 1;
             }
-            for (uint32_t bits = todo_s; bits; bits &= bits - 1) {
+            for (uint32_t bits = m_eq; bits; bits &= bits - 1) {
                 const int r = __ffs(bits) - 1;
-                if (pos_s < GC_LIST_MAX) { M.list_g[pos_s] = base + tid * RUN + r; M.list_ph[pos_s] = word[r]; }
-                pos_s += 1;
+                if (p_eq < GC_LIST_WAIT) { M.list_g[p_eq] = base + tid * RUN + r; M.list_ph[p_eq] = word[r]; }
+                p_eq += 1;
             }
-            n_wait = min(GC_LIST_WAIT, n_wait + total_w);
-            n_spec = min(GC_LIST_MAX - GC_LIST_WAIT, n_spec + total_s);
+            n_old += t_old;
+            n_eq += t_eq;
         }
     }
     __syncthreads();
@@ -1986,6 +2051,13 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         const int32_t* gsk = S.gs + (size_t)M.list_g[tid] * TM_GS_DW;
         int step = ph == GC_REQ_OVER ? GCP_INIT : ph;   // the step this launch performs for the game
         if (ph == GC_SPEC_MARK) step = gsk[TM_GS_GC_HEAD0] < gsk[TM_GS_GC_TAIL0] ? GCP_MARK : GC_IDLE;
+        // a collection under way was begun by launches with n_gc collector workgroups - its shares, its counts per workgroup and
+        // its arrival count are cut for that many.  Met by a launch with another number (another range of games: a sub-batch
+        // here, the whole store there) it is left alone and the game is flagged: a misuse must raise, not corrupt free lists.
+        if (step != GCP_INIT && step != GC_SPEC_REQ && gsk[TM_GS_GC_NGC] != n_gc) {
+            step = GC_FOREIGN;
+            if (c == 0) atomicOr(&S.gs[(size_t)M.list_g[tid] * TM_GS_DW + TM_GS_ERR], TM_ERR_GC_GRID);
+        }
         M.list_step[tid] = step;
         if (tid < n_wait) M.age[tid] = (seq - gsk[TM_GS_GC_REQ_AT]) & 0x7FFFF;      // launches since the game asked (the launch number has 19 bits)
     }
@@ -2006,7 +2078,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         const int wgs[2] = {split ? n_m / 2 : n_m, split ? n_m - n_m / 2 : n_m}, off[2] = {0, split ? n_m / 2 : 0};
         const int tot[2] = {split ? cnt[0] : cnt[0] + cnt[1], split ? cnt[1] : cnt[0] + cnt[1]};
         int mark_j[2] = {0, 0};
-        int cost_left = deadline < 0 ? 1 << 20 : GC_COST_MAX, n_order = 0;      // (collector-only launches: nothing to hold up)
+        int cost_left = deadline < 0 ? 1 << 20 : (S.gc_cost_units > 0 ? S.gc_cost_units : GC_COST_MAX), n_order = 0;      // (collector-only launches: nothing to hold up)
         const int cm = n_gc >= 2 ? c - n_b : 0;           // index among the marking workgroups (< 0: not one of them)
         for (int pass = 0; pass < 4; ++pass) {            // bounded steps of the waiting games, of the others; the markings likewise
             const int cls = pass & 1, first = cls ? n_wait : 0, n = cls ? n_spec : n_wait;
@@ -2015,6 +2087,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                 const int step = M.list_step[k];
                 if ((pass < 2) == (step == GCP_MARK)) continue;
                 int my_part = -1, n_parts = 1, share = 0;
+                if (step == GC_FOREIGN) { M.list_parts[k] = 0; continue; }      // nobody arrives
                 if (step == GC_IDLE) {
                     // everybody just arrives
                 } else if (step != GCP_MARK) {
@@ -2050,6 +2123,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         bool any_left = false;
         if (!gc_arrive(gs, n_gc, leftover, any_left, !spec && step != GC_SPEC_REQ)) return;
         if (step == GCP_INIT || step == GC_SPEC_REQ) {
+            gs[TM_GS_GC_NGC] = n_gc;               // the collection is the work of launches with this many collector workgroups
             atomicExch(&gs[TM_GS_GC_TAIL], 1);
             atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF);
             gs[TM_GS_GC_TAIL0] = 1;
@@ -2110,9 +2184,6 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         const long long p0 = my_part < 0 ? 0 : my_part, p1 = my_part < 0 ? 0 : my_part + 1;      // share = [x * p0 / n_parts, x * p1 / n_parts)
         const GP P = game_ptrs(S, g);
         int32_t* gs = P.gs();
-#ifdef TM_GC_TIMING
-        const long long t_step0 = (long long)__builtin_readcyclecounter();
-#endif
         uint32_t* nmw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes);
         uint32_t* omw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes + bm_bytes);
         int32_t* queue = S.gc_queue + (size_t)g * N;
@@ -2392,9 +2463,6 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         }
         // ---- arrive ----
         __syncthreads();
-#ifdef TM_GC_TIMING   /* diagnostic build: cycles/16 part 0 spent in each step of this game's last collection -> control words 48 + step */
-        if (tid == 0 && my_part == 0) gs[48 + ph] = (ph == GCP_MARK ? gs[48 + ph] : 0) + (int)(((long long)__builtin_readcyclecounter() - t_step0) >> 4);
-#endif
         if (tid == 0) arrive(k, leftover);
         __syncthreads();
     }
@@ -2412,7 +2480,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     // The first workgroups of the grid are collectors: each looks after the garbage collections of a range of games, in
     // slices of S.gc_slice_cycles per launch (catch-up launches pass TM_SIM_GC_FULL: to completion), beside the
     // simulation workgroups - they are dispatched first and share the CUs with them (a k_sim_step wave needs 70 registers).
-    const int n_gc = gc_blocks(S.n_games);
+    const int n_gc = gc_blocks(S);
     if ((int)blockIdx.x < n_gc) {
         static_assert(sizeof(WaveLds) * WPB >= sizeof(GcLds), "collector scratch");
         // the dense request list: this launch appends under S.eval_parity; the other set of counters (the list the evaluator
@@ -2422,8 +2490,10 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
         gc_collector_block(S, flags, n_gc, *reinterpret_cast<GcLds*>(lds));
         return;
     }
-    const int g = ((int)blockIdx.x - n_gc) * WPB + w;
-    if (g >= S.n_games) return;
+    // simulation wave i takes game i, or - a launch over some of the games: the catch-up launches - game_list[i]
+    const int slot = ((int)blockIdx.x - n_gc) * WPB + w;
+    if (slot >= (S.game_list ? S.n_listed : S.n_games)) return;
+    const int g = S.game_list ? __builtin_amdgcn_readfirstlane(S.game_list[slot]) : slot;
     GP P = game_ptrs(S, g);
     WaveLds& L = lds[w];
     int32_t* gs = P.gs();
@@ -2492,6 +2562,28 @@ __global__ void k_sims_remaining(tm_store S, int32_t* out) {
         col = (ph != 0 && ph != GC_DONE && ph != GC_SPEC_REQ && ph != GC_SPEC_MARK) ? 1 : 0;
         r = (gs[TM_GS_SIM_TARGET] - gs[TM_GS_SIM_STARTED]) + (gs[TM_GS_PENDING] != 0 ? 1 : 0) + col;
     }
+    for (int d = 32; d >= 1; d >>= 1) { r = max(r, __shfl_xor(r, d, 64)); col += __shfl_xor(col, d, 64); }
+    if ((threadIdx.x & 63) == 0) { if (r > 0) atomicMax(out, r); if (col > 0) atomicAdd(out + 1, col); }
+}
+
+// the same, and the games that still need launches appended to `list` (out[2] = how many; zeroed by the caller)
+__global__ void k_sims_owing(tm_store S, int32_t* out, int32_t* list) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = 0, col = 0;
+    if (g < S.n_games) {
+        const int32_t* gs = S.gs + (size_t)g * TM_GS_DW;
+        const int ph = gs[TM_GS_GC_PHASE] & 15;
+        col = (ph != 0 && ph != GC_DONE && ph != GC_SPEC_REQ && ph != GC_SPEC_MARK) ? 1 : 0;
+        r = (gs[TM_GS_SIM_TARGET] - gs[TM_GS_SIM_STARTED]) + (gs[TM_GS_PENDING] != 0 ? 1 : 0) + col;
+        // (a game whose collection these launches will not touch - TM_ERR_GC_GRID - never finishes: nobody waits for it,
+        // the caller finds the flag)
+        if (gs[TM_GS_ERR] & TM_ERR_GC_GRID) { r = 0; col = 0; }
+    }
+    const uint64_t owing = __ballot(r > 0);
+    int base = 0;
+    if ((threadIdx.x & 63) == 0 && owing != 0ull) base = atomicAdd(out + 2, __popcll(owing));
+    base = __shfl(base, 0, 64);
+    if (r > 0) list[base + __popcll(owing & ((1ull << (threadIdx.x & 63)) - 1ull))] = g;
     for (int d = 32; d >= 1; d >>= 1) { r = max(r, __shfl_xor(r, d, 64)); col += __shfl_xor(col, d, 64); }
     if ((threadIdx.x & 63) == 0) { if (r > 0) atomicMax(out, r); if (col > 0) atomicAdd(out + 1, col); }
 }
@@ -2858,10 +2950,12 @@ int tm_tree_remove_nodes(const tm_store* s, const uint8_t* mask, void* stream) {
 }
 int tm_sim_step(const tm_store* s, int flags, void* stream) {
     if (!s->eval_list || !s->eval_cnt) return (int)hipErrorInvalidValue;      // (a tm_store of an older header: no request list)
+    if (s->game_list && (s->n_listed < 0 || s->n_listed > s->n_games)) return (int)hipErrorInvalidValue;
     // the launch number (bits 8.. of the kernel's flags): what orders a game's wave and its collector workgroup, which
     // only ever hand over at kernel boundaries.  Any two launches that touch the same game differ in it.
     flags = (flags & 0xFF) | (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
-    const dim3 grid((s->n_games + WPB - 1) / WPB + gc_blocks(s->n_games)), block(64 * WPB);
+    const int n_waves = s->game_list ? s->n_listed : s->n_games;       // simulation waves; the collectors are those of all n_games
+    const dim3 grid((n_waves + WPB - 1) / WPB + gc_blocks(*s)), block(64 * WPB);
     if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
         hipLaunchKernelGGL(k_sim_step<true>, grid, block, WPB * sizeof(MtLds), (hipStream_t)stream, *s, flags);
     else
@@ -2871,7 +2965,7 @@ int tm_sim_step(const tm_store* s, int flags, void* stream) {
 int tm_gc_step(const tm_store* s, void* stream) {
     // the collector workgroups alone, no time limit: one step of every collection under way
     const int flags = TM_SIM_GC_FULL | (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
-    const dim3 grid(gc_blocks(s->n_games)), block(64 * WPB);
+    const dim3 grid(gc_blocks(*s)), block(64 * WPB);
     if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
         hipLaunchKernelGGL(k_sim_step<true>, grid, block, WPB * sizeof(MtLds), (hipStream_t)stream, *s, flags);
     else
@@ -2887,6 +2981,13 @@ int tm_sims_remaining(const tm_store* s, int32_t* out, void* stream) {
     hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(int32_t), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_sims_remaining, dim3((s->n_games + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s, out);
+    return TM_LAUNCH_CHECK();
+}
+int tm_sims_owing(const tm_store* s, int32_t* out, int32_t* list, void* stream) {
+    if (!list) return (int)hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(out, 0, 3 * sizeof(int32_t), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_sims_owing, dim3((s->n_games + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s, out, list);
     return TM_LAUNCH_CHECK();
 }
 int tm_eval_render(const tm_store* s, int8_t* out, void* stream) {

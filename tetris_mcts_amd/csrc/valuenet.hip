@@ -108,26 +108,16 @@ namespace tmcts_vn {
 //   T4[(s/4)*64 + l][s%4]
 // ===================================================================================================
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#ifndef TM_SCHED_REGION_QUADS
-#define TM_SCHED_REGION_QUADS 6
-#endif
+constexpr int SCHED_REGION_QUADS = 6;   // conv_mfma closes its scheduling region every this many quads of MFMA steps
 constexpr int PREP_W2 = 0, PREP_W3 = 9216, PREP_W1 = 18432, PREP_TOTAL = 18432 + 458752;
 constexpr int A1CS = 145;   // conv1-output channel stride in LDS (18*8 = 144, +1 against bank conflicts)
 constexpr int A2CS = 97;    // conv2-output channel stride in LDS (16*6 = 96, +1)
-// TM_CONV_WG_PER_CU = 2: conv2's outputs live in registers until its last LDS read of a1 has been issued, so a2 can
+// Two workgroups per CU: conv2's outputs live in registers until its last LDS read of a1 has been issued, so a2 can
 // take a1's place; a wave then needs 19.4 KB instead of 31.8 KB and two workgroups (8 waves) fit a CU's 160 KB: the
-// vector-ALU phases of one wave (render, conv1, epilogues) run under the other wave's MFMAs.
-#ifndef TM_CONV_WG_PER_CU
-#define TM_CONV_WG_PER_CU 2   // measured (r01): 118 us -> 104 us per launch of 4096 states
-#endif
-#ifndef TM_CONV_SKIP
-#define TM_CONV_SKIP 0   // timing experiments only: bit 0 conv1, bit 1 conv2's MFMAs, bit 2 conv3's MFMAs compiled out
-#endif
-#if TM_CONV_WG_PER_CU == 2
+// vector-ALU phases of one wave (render, conv1, epilogues) run under the other wave's MFMAs (measured, r01: 118 us -> 104 us
+// per launch of 4096 states).
+constexpr int CONV_WG_PER_CU = 2;
 constexpr int WAVE_LDS = 32 * A1CS + 200;               // floats per wave: a1 (a2 overlays it), input
-#else
-constexpr int WAVE_LDS = 32 * A1CS + 32 * A2CS + 200;   // floats per wave: a1, a2, input
-#endif
 
 __global__ void k_vn_prepare(const float* __restrict__ P, float* __restrict__ prep) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,21 +187,14 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, const in
         }
         // Close the scheduling region every few quads: the group solver's cost grows steeply with the number of
         // groups in one region (all 36 quads in one region take minutes to compile).
-        if (q % TM_SCHED_REGION_QUADS == TM_SCHED_REGION_QUADS - 1) __builtin_amdgcn_sched_barrier(0);
+        if (q % SCHED_REGION_QUADS == SCHED_REGION_QUADS - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // Input: either int8 states [n][200], or (states == nullptr) the evaluation requests of the tree engine's dense list (ReqList
 // below): entry p = (request slot, packed observation of the slot's game, ENGINE_SPEC.md section 7), rendered here on the fly
 // (0 empty, 1 locked, -1 falling piece).
-#if TM_CONV_WG_PER_CU == 2 && !defined(TM_CONV_CAP256)
-#define TM_CONV_CAP256   // two waves per SIMD: 256 registers each
-#endif
-#ifdef TM_CONV_CAP256
-#define TM_CONV_WAVES 2
-#else
-#define TM_CONV_WAVES 1
-#endif
+constexpr int CONV_WAVES_PER_SIMD = 2;   // two workgroups per CU = two waves per SIMD: 256 registers each
 // The tree engine's dense request list (include/tetris_mcts_hip.h, tm_store::eval_list): `segs` segments with one counter
 // each under the current parity; entry d of segment sg is list[(sg + segs * (d / slots)) * slots + d % slots] = (request slot,
 // observation index).  Dense position p counts through the segments in order.
@@ -505,7 +488,7 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     });
     if (attr_err) return attr_err;
     int blocks = (n + 3) / 4;
-    if (blocks > 256 * TM_CONV_WG_PER_CU) blocks = 256 * TM_CONV_WG_PER_CU;   // resident workgroups, waves stride over the states
+    if (blocks > 256 * CONV_WG_PER_CU) blocks = 256 * CONV_WG_PER_CU;   // resident workgroups, waves stride over the states
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, rq,
                        max_nodes, n, scratch, SS, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS);
     if (n >= 8192)      // (request slots: the leaf-parallel kinds' seven per game)

@@ -104,9 +104,10 @@ class Model_VV:
         self.weights_epoch = next_weights_epoch()
         return res
 
-    def load(self, filename=EXP_PATH + "model_checkpoint"):
+    def load(self, filename=EXP_PATH + "model_checkpoint", verbose=True):
         if os.path.isfile(filename):
-            print("Loading model...", flush=True)
+            if verbose:
+                print("Loading model...", flush=True)
             ck = torch.load(filename, map_location=self.device)
             self.model.load_state_dict(ck["model_state_dict"])
             if ck.get("optimizer_state_dict"):
@@ -116,7 +117,7 @@ class Model_VV:
                     from sys import stderr
                     print("WARNING: optimizer state of %s not loaded (%s): the optimiser restarts with fresh moments"
                           % (filename, e), file=stderr, flush=True)
-        else:
+        elif verbose:
             print("Checkpoint not found, using default model", flush=True)
         self._flat = None
         self._prepared = None

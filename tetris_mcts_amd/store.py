@@ -16,7 +16,7 @@ GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, 
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18, MAX_TRACE=19, N_DROPPED=25,
           CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_SLICES=38,
           SIM_TARGET=40, SIM_STARTED=41, CYC_VERIFY=42, FIRST_MISS=28, PREFIX_SUM=29, N_WALK_MISS=43, POOL_FULL=44, GC_IN_MOVE=45, GC_REQ_AT=46,
-          LEAF_OBS=47, N_EVAL_SKIP=48, N_EVAL_CACHED=49)
+          LEAF_OBS=47, N_EVAL_SKIP=48, N_EVAL_CACHED=49, GC_NGC=50)
 
 _nq_cache = {}
 
@@ -56,7 +56,7 @@ class TreeStore:
 
     def __init__(self, n_games, max_nodes=100000, kind=KIND_VALUESIM, env_args=((20, 10), 1, 0, 0), gamma=0.999,
                  low=1, eval_slots=None, max_trace=1024, nq_size=1 << 20, online=False, min_visits_to_store=10,
-                 replay_cap=0, gc_slice_cycles=150000, gc_spec_nodes=None, dist_bins=50, dist_range=(0.0, 5000.0), device="cuda"):
+                 replay_cap=0, gc_slice_cycles=150000, gc_spec_nodes=None, gc_cost_units=0, gc_collectors=0, dist_bins=50, dist_range=(0.0, 5000.0), device="cuda"):
         if not torch.cuda.is_available():
             raise RuntimeError("tetris_mcts_amd needs a ROCm GPU (gfx950); there is no CPU path")
         shape, app, scoring, randomizer = env_args[0], env_args[1], env_args[2], env_args[3]
@@ -94,6 +94,7 @@ class TreeStore:
         self.t["obs_eval"] = z(G, N, 4, dtype=torch.float32) if kind in (KIND_VALUESIM, KIND_CPPAGENT) else None
         # the distributional agent's harvest (DistValueSimOnline.store_nodes): the freed nodes' distributions
         self.t["replay_dist"] = z(G, replay_cap, 64, dtype=torch.float32) if (kind == KIND_DIST and online and replay_cap > 0) else None
+        self.t["game_list"] = None       # (tm_store::game_list: the native loop's catch-up launches set it in their own copies)
         self.t["nq_table"] = norm_quantile_table(nq_size, dev)
         # TM_KIND_DIST only: the nodes' value distributions, the evaluator's output, norm_quantile in double
         is_dist = kind == KIND_DIST
@@ -114,7 +115,7 @@ class TreeStore:
             if typ is C.c_void_p:
                 setattr(s, name, self.t[name].data_ptr() if self.t[name] is not None else None)
         s.dist_bins, s.dist_vmin, s.dist_vmax = int(dist_bins), float(dist_range[0]), float(dist_range[1])
-        s.eval_parity, s.eval_epoch = 0, 0
+        s.eval_parity, s.eval_epoch, s.n_listed, s.gc_cost_units, s.gc_collectors = 0, 0, 0, int(gc_cost_units or 0), int(gc_collectors or 0)
         self.s = s
         self.stats_buf = torch.zeros(G, 3, 7, dtype=torch.float32, device=dev)
         self.action_buf = torch.zeros(G, dtype=torch.int32, device=dev)
@@ -204,10 +205,10 @@ class TreeStore:
         h = self._search.get((int(n_sub), int(ev_every)))
         if h is None:
             return None
-        out = (C.c_double * 10)()
-        self.L.tm_search_stats(h, out, 10, int(bool(reset)))
+        out = (C.c_double * 11)()
+        self.L.tm_search_stats(h, out, 11, int(bool(reset)))
         keys = ("runs", "tree_launches", "catchup_launches", "timed", "tree_ms_sum", "nn_ms_sum", "n_sub", "gc_launches",
-                "loop_ms_sum", "loop_sims")
+                "loop_ms_sum", "loop_sims", "catchup_waves")
         return dict(zip(keys, list(out)))
 
     def sim_step(self, flags):
