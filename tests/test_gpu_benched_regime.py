@@ -45,11 +45,14 @@ class _OracleGame:
         return act, stats, ended
 
 
-def _run(oracle, name, seeds, sample, moves, sims=500, max_nodes=100000, n_sub=1, check_tree=True, **agent_kw):
+def _run(oracle, name, seeds, sample, moves, sims=500, max_nodes=100000, n_sub=1, check_tree=True, checkpoint=None, **agent_kw):
     """Batch of len(seeds) games on the GPU; games `sample` (indices) are checked against their own oracle every move."""
     from tetris_mcts_amd import agents
     from tetris_mcts_amd.pyTetris import Tetris
     model, params = _bench_model()
+    if checkpoint:
+        model.load(checkpoint, verbose=False)
+        params = model.flat_params().cpu().numpy()
     env_args = ((20, 10), 1, 0, 0)
     seeds = np.asarray(seeds, dtype=np.int64)
     G = len(seeds)
@@ -102,6 +105,21 @@ def test_500_sims_full_pool_sampled_seeds(oracle, name, moves):
     seeds = [BASE_SEED + g for g in (0, 1, 1337, 4095)]
     agent, orc = _run(oracle, name, seeds, sample=[0, 1, 2, 3], moves=moves, n_sub=1 if name == "ValueSimC" else 2)
     assert int(agent.store.t["gs"][:, 19].max().item()) > 64       # the LDS trace buffer was flushed at least once
+
+
+def test_sampled_games_under_the_trained_checkpoint(oracle):
+    """The regime self-play lives in: the value net bench.py's `trained_net` object runs under (the committed checkpoint of an
+    online run; outputs scaled to [0, 13 508] x [0.1, 2.5e7] instead of the random-init net's [0, 100] x [0.1, 1000]) - every
+    simulation expands a node, pools fill within ten moves and the trees that survive a move are large.  256 games x 500
+    simulations, 30 000-node pools, 26 moves: three games against their oracles through their collections, whole trees."""
+    import os
+    import bench
+    ck = os.path.join(bench.ROOT, bench.TRAINED_CHECKPOINT)
+    seeds = BASE_SEED + np.arange(256)
+    agent, orc = _run(oracle, "ValueSim", seeds, sample=[0, 100, 255], moves=26, max_nodes=30000, checkpoint=ck)
+    gs = agent.store.t["gs"].cpu().numpy()
+    assert gs[:, 9].sum() > 256 and min(o.a.n_gc for o in orc) >= 1          # collections everywhere, in the checked games too
+    assert gs[:, 7].sum() > 0.95 * gs[:, 8].sum()                            # (nearly) every simulation expands
 
 
 def test_traces_beyond_128_and_a_collection_at_the_full_pool(oracle):

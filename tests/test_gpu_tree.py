@@ -416,7 +416,10 @@ def test_online_cpp_agent_training_sets(oracle, golden_dir, idx):
     oa.update_root(og)
     mem = ro.OnlineMemory(r["policy"], r["memory_size"], r["episodes_per_train"], r["growth"])
     seen, n_gc = 0, 0
-    for m, act in enumerate(r["actions"]):
+    # (policies 0 and 3 - one episode-driven, one memory-driven - replay the reference's whole 900-move run; 1 and 2 its first
+    # 500 moves: three to four trainings each, at half the suite time)
+    n_moves = len(r["actions"]) if r["policy"] in (0, 3) else 500
+    for m, act in enumerate(r["actions"][:n_moves]):
         move[0] = m
         got = agent.play()
         assert got == act == oa.play(r["sims"]), m
@@ -439,12 +442,13 @@ def test_online_cpp_agent_training_sets(oracle, golden_dir, idx):
             agent.update_root(game)
             og.reset()
             oa.update_root(og)
-    assert agent.store.counter("N_GC") == oa.n_gc >= 7
-    assert len(want_calls) >= 4 and got_calls == want_calls
+    full = n_moves == len(r["actions"])
+    assert agent.store.counter("N_GC") == oa.n_gc >= (7 if full else 3)
+    assert len(want_calls) >= (4 if full else 2) and got_calls == want_calls
     if r["policy"] in (0, 1):
         # episode-driven policies train at the same moves as the reference's own run (the slip only changes how many
         # tuples a GC yields, which moves the memory-driven policies 2 and 3)
-        assert [c["move"] for c in got_calls] == [c["move"] for c in r["train_calls"]]
+        assert [c["move"] for c in got_calls] == [c["move"] for c in r["train_calls"] if c["move"] < n_moves]
 
 
 @pytest.mark.parametrize("idx", [0, 1])

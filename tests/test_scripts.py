@@ -52,7 +52,7 @@ def test_pmc_traffic_summary_and_bench_reader(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
     os.makedirs(tmp_path / "profiles")
-    os.replace(oj, tmp_path / bench.PMC_FILE)
+    os.replace(oj, tmp_path / "profiles" / "r05_pmc_traffic_of_this_test.json")      # (a file bench.PMC_FILE's pattern matches)
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.pmc_traffic(["tmcts::k_sim_step<false>"], "K1") == 1024.0 * (20.0 + 6.0)
     assert bench.pmc_traffic(["tmcts::k_sim_step<false>"], "K1", 2.0) == 1024.0 * (40.0 + 6.0)

@@ -35,7 +35,7 @@ constexpr uint16_t mk(const CellList& l) {
     return m;
 }
 #define TM_CL(a, b, c, d, e, f, g, h) mk(CellList{{{a, b}, {c, d}, {e, f}, {g, h}}})
-__device__ const uint16_t PIECE_MASK[7][4] = {
+constexpr uint16_t PIECE_MASK_C[7][4] = {
     /* I */ {TM_CL(0,1,1,1,2,1,3,1), TM_CL(2,0,2,1,2,2,2,3), TM_CL(0,2,1,2,2,2,3,2), TM_CL(1,0,1,1,1,2,1,3)},
     /* O */ {TM_CL(1,0,2,0,1,1,2,1), TM_CL(1,0,2,0,1,1,2,1), TM_CL(1,0,2,0,1,1,2,1), TM_CL(1,0,2,0,1,1,2,1)},
     /* T */ {TM_CL(1,0,0,1,1,1,2,1), TM_CL(1,0,1,1,2,1,1,2), TM_CL(0,1,1,1,2,1,1,2), TM_CL(1,0,0,1,1,1,1,2)},
@@ -45,6 +45,22 @@ __device__ const uint16_t PIECE_MASK[7][4] = {
     /* L */ {TM_CL(2,0,0,1,1,1,2,1), TM_CL(1,0,1,1,1,2,2,2), TM_CL(0,1,1,1,2,1,0,2), TM_CL(0,0,1,0,1,1,1,2)},
 };
 #undef TM_CL
+// the four cells of an orientation as box positions (4*row + col), ascending, one nibble each: what pack_obs walks
+constexpr uint16_t mk_cells(uint16_t mask) {
+    uint16_t out = 0;
+    int n = 0;
+    for (int bit = 0; bit < 16; ++bit)
+        if ((mask >> bit) & 1u) { out = (uint16_t)(out | (bit << (4 * n))); n += 1; }
+    return out;
+}
+#define TM_ROW(f, p) {f(PIECE_MASK_C[p][0]), f(PIECE_MASK_C[p][1]), f(PIECE_MASK_C[p][2]), f(PIECE_MASK_C[p][3])}
+#define TM_ID(x) (x)
+__device__ const uint16_t PIECE_MASK[7][4] = {TM_ROW(TM_ID, 0), TM_ROW(TM_ID, 1), TM_ROW(TM_ID, 2), TM_ROW(TM_ID, 3),
+                                              TM_ROW(TM_ID, 4), TM_ROW(TM_ID, 5), TM_ROW(TM_ID, 6)};
+__device__ const uint16_t PIECE_CELLS[7][4] = {TM_ROW(mk_cells, 0), TM_ROW(mk_cells, 1), TM_ROW(mk_cells, 2), TM_ROW(mk_cells, 3),
+                                               TM_ROW(mk_cells, 4), TM_ROW(mk_cells, 5), TM_ROW(mk_cells, 6)};
+#undef TM_ROW
+#undef TM_ID
 
 // SRS kicks (dx, dy-up), index [set][from_rot*2 + ccw][test]; set 0 = JLSTZ, 1 = I (ENGINE_SPEC.md section 4)
 __device__ const int8_t KICKS[2][8][5][2] = {
@@ -121,15 +137,36 @@ __device__ __forceinline__ bool collides(const uint16_t* rows, uint32_t mask, in
     return hit != 0;
 }
 
-__device__ __forceinline__ void spawn(const uint16_t* rows, Piece& p, const EngCfg& cfg) {
-    p.piece = piece_at(p.seed, p.piece_count, cfg.randomizer);
+// piece_at(seed, i) by the lanes of a wave together (every lane calls it with the same wave-uniform arguments and gets the
+// result): the six draws of the 7-bag shuffle are independent - lane t computes r_t, the six swaps follow on wave-uniform
+// values.  The seven successors of an expansion share seed and piece count, and at least one of them (the hard drop) locks
+// and spawns in every expansion: one such call replaces a 300-instruction shuffle on a single lane.
+__device__ __forceinline__ int wave_piece_at(uint32_t seed, uint32_t i, int randomizer, int lane) {
+    if (randomizer == 1) return (int)(rnd32(seed, i) % 7u);
+    const uint32_t k = i / 7u;
+    const uint32_t t_l = (uint32_t)(lane >= 1 && lane <= 6 ? lane : 1);
+    const uint32_t r_l = rnd32(seed, 8u * k + t_l) % (t_l + 1u);
+    uint32_t perm = 0x6543210u;
+    for (int t = 6; t >= 1; --t) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)r_l, t);
+        const uint32_t a = (perm >> (4 * t)) & 0xFu, b = (perm >> (4 * r)) & 0xFu;
+        perm &= ~((0xFu << (4 * t)) | (0xFu << (4 * r)));
+        perm |= b << (4 * t);
+        if ((uint32_t)t != r) perm |= a << (4 * r);
+    }
+    return (int)((perm >> (4 * (i % 7u))) & 0xFu);
+}
+
+// `next_piece` >= 0: piece_at(p.seed, p.piece_count) as the caller has already computed it (wave_piece_at)
+__device__ __forceinline__ void spawn(const uint16_t* rows, Piece& p, const EngCfg& cfg, int next_piece = -1) {
+    p.piece = next_piece >= 0 ? next_piece : piece_at(p.seed, p.piece_count, cfg.randomizer);
     p.piece_count += 1;
     p.rot = 0; p.x = 3; p.y = 0; p.drop_ctr = 0;
     if (collides(rows, PIECE_MASK[p.piece][0], 3, 0)) p.flags |= 1;
 }
 
 // ENGINE_SPEC.md section 5.  line_stats (may be null) is a per-environment side record.
-__device__ __forceinline__ void lock_piece(uint16_t* rows, Piece& p, const EngCfg& cfg, int* line_stats) {
+__device__ __forceinline__ void lock_piece(uint16_t* rows, Piece& p, const EngCfg& cfg, int* line_stats, int next_piece = -1) {
     uint32_t mask = PIECE_MASK[p.piece][p.rot];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -171,7 +208,7 @@ __device__ __forceinline__ void lock_piece(uint16_t* rows, Piece& p, const EngCf
     } else {
         p.combo = -1;
     }
-    spawn(rows, p, cfg);
+    spawn(rows, p, cfg, next_piece);
 }
 
 // ENGINE_SPEC.md section 4: one play(a).  The piece locks at ONE place in the code: the three ways to lock (hard drop, a
@@ -180,7 +217,9 @@ __device__ __forceinline__ void lock_piece(uint16_t* rows, Piece& p, const EngCf
 // once per call site.
 // `drop_rows` >= 0: the caller already knows how many rows the piece can fall (computed by the lanes of a wave together,
 // hard_drop_rows below); -1: found here, row by row.
-__device__ __forceinline__ void play(uint16_t* rows, Piece& p, const EngCfg& cfg, int a, int* line_stats, int drop_rows = -1) {
+// `next_piece` >= 0: the piece a lock would spawn, piece_at(p.seed, p.piece_count), already computed (wave_piece_at).
+__device__ __forceinline__ void play(uint16_t* rows, Piece& p, const EngCfg& cfg, int a, int* line_stats, int drop_rows = -1,
+                                     int next_piece = -1) {
     if (p.flags & 1) return;
     bool do_lock = false;
     uint32_t mask = PIECE_MASK[p.piece][p.rot];
@@ -228,7 +267,7 @@ __device__ __forceinline__ void play(uint16_t* rows, Piece& p, const EngCfg& cfg
             else do_lock = true;
         }
     }
-    if (do_lock) lock_piece(rows, p, cfg, line_stats);
+    if (do_lock) lock_piece(rows, p, cfg, line_stats, next_piece);
 }
 
 // How many rows the falling piece of the game in `slot` can fall (the hard drop's loop), by the lanes of a wave together:
@@ -271,15 +310,14 @@ __device__ inline void pack_obs(const uint32_t* g, uint32_t* o) {
     if ((b >> 8) & 1) { o[10] = 0xFFFFFFFFu; o[11] = 1u; return; }
     int piece = a & 0xFF, rot = (a >> 8) & 0xFF;
     int x = (int)(int8_t)((a >> 16) & 0xFF), y = (int)(int8_t)((a >> 24) & 0xFF);
-    uint32_t mask = PIECE_MASK[piece][rot];
+    // the piece's four cells as row * 10 + col, ascending (box positions ascend row-major, which is ascending row * 10 + col)
+    const uint32_t pos = PIECE_CELLS[piece][rot];
     uint32_t cells = 0;
-    int n = 0;
-    // box bits ascend row-major, which is ascending row*10+col as well
-    for (int bit = 0; bit < 16; ++bit)
-        if ((mask >> bit) & 1u) {
-            cells |= (uint32_t)((y + (bit >> 2)) * 10 + x + (bit & 3)) << (8 * n);
-            n += 1;
-        }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int bit = (int)((pos >> (4 * n)) & 0xFu);
+        cells |= (uint32_t)((y + (bit >> 2)) * 10 + x + (bit & 3)) << (8 * n);
+    }
     o[10] = cells;
     o[11] = 0;
 }

@@ -484,10 +484,12 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
     wave_sync();
     EngCfg cfg{S.app, S.scoring, S.randomizer};
     const int drop = hard_drop_rows(L.slots[7], lane);       // for the successor of action 3: 21 lanes instead of a 20-step loop in one
+    // the piece a lock spawns: the same for every successor (seed and piece count are the parent's), the lanes' work (engine.h)
+    const int next_piece = wave_piece_at(L.slots[7][13], L.slots[7][12], S.randomizer, lane);
     if (lane < 7) {
         Piece p;
         load_fields(L.slots[lane], p);
-        play(reinterpret_cast<uint16_t*>(L.slots[lane]), p, cfg, lane, nullptr, drop);
+        play(reinterpret_cast<uint16_t*>(L.slots[lane]), p, cfg, lane, nullptr, drop, next_piece);
         store_fields(L.slots[lane], p);
     }
     wave_sync();
