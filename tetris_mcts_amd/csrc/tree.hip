@@ -1879,6 +1879,7 @@ constexpr int GC_LIST_MAX = 256, GC_LIST_WAIT = 64;     // collecting games look
 constexpr int GC_COST_MAX = 12;      // per launch: cost units of the steps whose shares are done without looking at the clock
                                      // (init 1, count 1, write 2, nodes 5, observations 5: about 5 microseconds a unit)
 constexpr int GC_RING = 32;          // chunks of own discoveries a workgroup remembers while marking
+constexpr int GC_MARK_WGS_PER_GAME = 5;      // marking workgroups a marking game gets at most (r04's 32 marking workgroups over its ~7 marking games)
 struct GcLds {
     int scan[8];                     // Grp<256> scratch
     int n_list;
@@ -2104,6 +2105,11 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                     if (n_mark <= n_w) {
                         n_parts = n_w / n_mark + (j < n_w % n_mark ? 1 : 0);
                         my_part = (mine && cx % n_mark == j) ? cx / n_mark : -1;
+                        // ... at most GC_MARK_WGS_PER_GAME of them: a marking is a chain of dependent round trips that more
+                        // workgroups do not shorten beyond that, and every workgroup that marks to the launch's deadline takes
+                        // memory bandwidth from the simulation waves (with a few games marking - the random-init net's steady
+                        // state - the others stay idle; under the trained net's load all of them work)
+                        if (n_parts > GC_MARK_WGS_PER_GAME) { n_parts = GC_MARK_WGS_PER_GAME; if (my_part >= GC_MARK_WGS_PER_GAME) my_part = -1; }
                     } else {
                         // more games marking than workgroups: workgroup j % n_w takes the whole of game j, its time shared
                         my_part = (mine && j % n_w == cx) ? 0 : -1;
