@@ -257,6 +257,8 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx,
     elapsed, n_exp, n_sims, n_eval = head["elapsed"], head["n_exp"], head["n_sims"], head["n_eval"]
     mean_len = head["tr_sum"] / max(n_sims, 1.0)
     workload_key = "%s G=%d sims=%d pool=%d warmup=%d steps=%d split=%d" % (name, G, sims, max_nodes, warmup, steps, NS)
+    if checkpoint:       # (other weights, other trees: the PMC passes of the random-init workload do not describe this one)
+        workload_key += " checkpoint=%s" % os.path.basename(checkpoint)
 
     def gc_block(r):
         return {"collections": int(r["n_gc"]), "collector_launches_x_games": int(r["gc_slices"]),
@@ -479,8 +481,12 @@ def main():
     ctx = dict(rank=rank, world=world)
     sims = args.sims if args.sims is not None else (100 if args.agent == "Vanilla" else 500)
     args.sims = sims
-    out, model = run_agent(args, args.agent, sims, args.warmup, args.steps, args.steady_warmup, args.steady_steps, ctx,
-                           checkpoint=args.checkpoint and os.path.abspath(args.checkpoint))
+    ckpt = None
+    if args.checkpoint:      # (relative to the working directory, else to the repository; a missing file is an error, not a random net)
+        ckpt = next((c for c in (os.path.abspath(args.checkpoint), os.path.join(ROOT, args.checkpoint)) if os.path.isfile(c)), None)
+        if ckpt is None:
+            sys.exit("bench.py: checkpoint %s not found" % args.checkpoint)
+    out, model = run_agent(args, args.agent, sims, args.warmup, args.steps, args.steady_warmup, args.steady_steps, ctx, checkpoint=ckpt)
     others = {}
     want_others = args.others == "all" or (args.others == "auto" and world == 1 and args.agent == "ValueSim" and not args.online
                                            and args.backend == "hip" and args.split == 1 and not args.checkpoint)
