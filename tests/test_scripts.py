@@ -61,9 +61,9 @@ def test_pmc_traffic_summary_and_bench_reader(tmp_path, monkeypatch):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The driver's line as this round's final run printed it (profiles/r04_bench_valuesim_4096x500.json): the keys of the bench
+    """The driver's line as this round's final run printed it (profiles/r05_bench_valuesim_4096x500.json): the keys of the bench
     contract, the two objects of the hot-path tier (roofline, cpu_baseline) and this repo's additions, with consistent numbers."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_valuesim_4096x500.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_valuesim_4096x500.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -84,6 +84,16 @@ def test_committed_bench_line_keeps_the_contract():
     assert d["value"] * d["ms_per_step"] * 1e-3 <= d["config"]["games_per_gpu"] * d["config"]["sims_per_move"]
     assert set(d["other_configs"]) == {"ValueSimLP", "DistValueSim", "Vanilla"} and all("error" not in v or v["error"] is None for v in d["other_configs"].values())
     assert d["steady_state"]["ms_per_step"] < 1.1 * d["ms_per_step"]        # the steady state within 10 % of the headline
+    # the metric's second half: the same windows under the committed checkpoint, and every other line's number as a top-level scalar
+    t = d["trained_net"]
+    assert os.path.isfile(os.path.join(ROOT, t["checkpoint"]["file"])) and t["error_games"] == 0 and t["steady_state"]["error_games"] == 0
+    assert t["steady_state"]["lines_per_1000_moves"] > 50 and t["mean_trace_len"] < d["mean_trace_len"]
+    import hashlib
+    assert hashlib.sha256(open(os.path.join(ROOT, t["checkpoint"]["file"]), "rb").read()).hexdigest()[:16] == t["checkpoint"]["sha256_16"]
+    for key, src in (("steady_value", d["steady_state"]), ("lp_value", d["other_configs"]["ValueSimLP"]), ("dist_value", d["other_configs"]["DistValueSim"]),
+                     ("vanilla_value", d["other_configs"]["Vanilla"]), ("trained_value", t)):
+        assert d[key] == src["value"], key
+    assert d["trained_steady_lines_per_1000_moves"] == t["steady_state"]["lines_per_1000_moves"]
 
 
 def test_bench_gpus_n_without_n_devices_says_so():
