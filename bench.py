@@ -113,7 +113,7 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx,
         kw.update(dict(online=True, min_visits_to_store=10, replay_cap=16384) if args.online else dict(online=False))
     agent = getattr(agents, name)(sims=sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=max_nodes,
                                   n_sub=NS, ev_every=EV_EVERY, gc_slice_cycles=args.gc_slice_cycles, gc_spec_nodes=args.gc_spec_nodes,
-                                  gc_cost_units=args.gc_cost_units, gc_collectors=args.gc_collectors, gc_side_cycles=args.gc_side_cycles, **kw)
+                                  gc_cost_units=args.gc_cost_units, gc_collectors=args.gc_collectors, **kw)
     agent.update_root(game)
     torch.cuda.synchronize()
     S = agent.store
@@ -297,7 +297,7 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx,
             "workload_key": workload_key,
             "games_per_gpu": G, "sims_per_move": sims, "agent": name, "max_nodes": max_nodes,
             "valuenet_backend": None if is_vanilla else args.backend, "sub_batches": NS, "online": bool(args.online),
-            "gc_slice_cycles": args.gc_slice_cycles, "gc_spec_nodes": args.gc_spec_nodes, "gc_cost_units": args.gc_cost_units, "gc_collectors": args.gc_collectors, "gc_side_cycles": args.gc_side_cycles,
+            "gc_slice_cycles": args.gc_slice_cycles, "gc_spec_nodes": args.gc_spec_nodes, "gc_cost_units": args.gc_cost_units, "gc_collectors": args.gc_collectors,
             "checkpoint": checkpoint and os.path.relpath(checkpoint, ROOT),
         },
         "sims_per_sec": n_sims / elapsed,
@@ -421,7 +421,6 @@ def main():
                     help="free nodes below which a game's tree is marked while it goes on simulating (default: the store's)")
     ap.add_argument("--gc-cost-units", type=int, default=0, help="bounded collection steps a launch takes on, in cost units (0: the store's default)")
     ap.add_argument("--gc-collectors", type=int, default=0, help="collector workgroups per launch (0: the store's default, 128)")
-    ap.add_argument("--gc-side-cycles", type=int, default=0, help="marking allowance of the collector-only launch beside every evaluator call (0: none)")
     ap.add_argument("--checkpoint", default=None, help="value-net checkpoint for the measured agent (default: random init under manual_seed(0))")
     ap.add_argument("--online", action="store_true", help="harvest training tuples at GC and all-gather them every move")
     ap.add_argument("--steady-warmup", type=int, default=75, help="the steady-state window starts after this many moves")

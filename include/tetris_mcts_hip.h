@@ -195,10 +195,6 @@ typedef struct tm_store {
     int32_t gc_cost_units; /* cost units of bounded collection steps (init / count 1, write 2, re-insertion of nodes / observations 5
                               each: about 5 microseconds a unit) the collector workgroups of one tm_sim_step launch take on; 0: the
                               default (12).  More units serve more collections per launch and make the launch longer. */
-    int32_t gc_side_cycles; /* > 0: tm_search_run launches the collector workgroups once more per simulation - alone, on a stream
-                              of their own, BESIDE the evaluator's kernels (which touch nothing a collection touches), with this
-                              marking allowance - so that a collection advances two steps per simulation and the marking gets
-                              its time without the tree kernel waiting for it.  0: off. */
     int32_t gc_collectors; /* collector workgroups per tm_sim_step launch (half for the bounded steps, half for the marking); 0: the
                               default (128), at most 128.  A collection must be continued by launches with the same number. */
 } tm_store;
@@ -244,8 +240,6 @@ int tm_sims_owing(const tm_store *s, int32_t *out /* device int[3] */, int32_t *
 /* one step of every garbage collection under way (the collector workgroups of tm_sim_step alone, no simulation): what the
  * driver launches instead of whole simulation launches while it waits for collections at the end of a move */
 int tm_gc_step(const tm_store *s, void *stream);
-/* the same with the launch's time allowance (s->gc_slice_cycles) for the marking: what a caller launches beside its evaluator */
-int tm_gc_slice(const tm_store *s, void *stream);
 #define TM_SIM_BACKUP 1  /* finish the pending simulation: backup with eval_v/eval_var */
 #define TM_SIM_FRONT 2   /* start one: select, expand, post evaluation requests into eval_obs */
 #define TM_SIM_GC_FULL 4 /* a game that is collecting garbage finishes the collection in this launch (catch-up launches) */

@@ -25,7 +25,7 @@ class TmStore(C.Structure):
         ("node_dist", vp), ("eval_dist", vp), ("nq_table_d", vp), ("dist_vmin", f64), ("dist_vmax", f64), ("dist_bins", i32),
         ("gc_spec_nodes", i32),
         ("eval_list", vp), ("eval_cnt", vp), ("obs_eval", vp), ("eval_parity", i32), ("eval_epoch", i32),
-        ("replay_dist", vp), ("game_list", vp), ("n_listed", i32), ("gc_cost_units", i32), ("gc_side_cycles", i32), ("gc_collectors", i32),
+        ("replay_dist", vp), ("game_list", vp), ("n_listed", i32), ("gc_cost_units", i32), ("gc_collectors", i32),
     ]
 
 
@@ -47,7 +47,6 @@ SYMBOLS = {
     "tm_sims_remaining": [C.POINTER(TmStore), vp, vp],
     "tm_sims_owing": [C.POINTER(TmStore), vp, vp, vp],
     "tm_gc_step": [C.POINTER(TmStore), vp],
-    "tm_gc_slice": [C.POINTER(TmStore), vp],
     "tm_eval_render": [C.POINTER(TmStore), vp, vp],
     "tm_root_stats": [C.POINTER(TmStore), vp, vp, vp],
     "tm_export_game": [C.POINTER(TmStore), i32, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -39,7 +39,7 @@ class TreeAgent(Agent):
     def __init__(self, sims=100, max_nodes=500000, env=None, env_args=None, node_saver=None, projection=True,
                  min_visits=30, n_games=None, gamma=0.999, online=False, min_visits_to_store=10, replay_cap=0,
                  max_trace=1024, nq_size=1 << 20, reset_on_pool_exhaustion=True, n_sub=1, ev_every=0,
-                 gc_slice_cycles=150000, gc_spec_nodes=None, gc_cost_units=0, gc_collectors=0, gc_side_cycles=0, **kwargs):
+                 gc_slice_cycles=150000, gc_spec_nodes=None, gc_cost_units=0, gc_collectors=0, **kwargs):
         super().__init__(**kwargs)
         if not projection:
             raise NotImplementedError("projection=False is broken in the reference itself (ValueSim.py:73-74)")
@@ -54,7 +54,7 @@ class TreeAgent(Agent):
         self._store_kwargs = dict(kind=self.kind, env_args=self.env_args, gamma=gamma, low=self.low, online=online,
                                   min_visits_to_store=min_visits_to_store, replay_cap=replay_cap, max_trace=max_trace,
                                   nq_size=nq_size, gc_slice_cycles=gc_slice_cycles, gc_spec_nodes=gc_spec_nodes,
-                                  gc_cost_units=gc_cost_units, gc_collectors=gc_collectors, gc_side_cycles=gc_side_cycles)
+                                  gc_cost_units=gc_cost_units, gc_collectors=gc_collectors)
         self.n_sub, self.ev_every = int(n_sub), int(ev_every)
         self._pending_events, self.loop_events, self.catchup_launches = [], dict(timed=0, nn_ms_sum=0.0, tree_ms_sum=0.0), 0
         self.store = None

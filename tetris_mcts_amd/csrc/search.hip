@@ -33,11 +33,6 @@ struct tm_search {
     int32_t* rem_host = nullptr;
     int32_t* owing_dev = nullptr;    // [n_games] the games that owe launches, per sub-batch at its first game (tm_sims_owing)
     long long extra_waves = 0;       // simulation waves of the catch-up launches (a full launch has n_games of them)
-    // tm_store::gc_side_cycles: a collector-only launch beside every evaluator call, on a stream of its own per sub-batch
-    std::vector<hipStream_t> side;
-    std::vector<hipEvent_t> ev_tree, ev_side;
-    std::vector<char> side_pending;
-    long long side_launches = 0;
     // HIP events around the regular launches of a move (sub-batch 0's stream): the time the per-kernel figures must add up to
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
     double loop_ms = 0;
@@ -139,22 +134,6 @@ int tm_search_create(tm_search** out, const tm_store* s, int n_sub, int ev_every
         if (e != hipSuccess) return fail((int)e);
         h->ev_done.push_back(d);
     }
-    if (s->gc_side_cycles > 0) {
-        for (int k = 0; k < n_sub; ++k) {
-            hipStream_t ss = nullptr;
-            e = hipStreamCreateWithFlags(&ss, hipStreamNonBlocking);
-            if (e != hipSuccess) return fail((int)e);
-            h->side.push_back(ss);
-            hipEvent_t a, b;
-            e = hipEventCreateWithFlags(&a, hipEventDisableTiming);
-            if (e != hipSuccess) return fail((int)e);
-            h->ev_tree.push_back(a);
-            e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
-            if (e != hipSuccess) return fail((int)e);
-            h->ev_side.push_back(b);
-            h->side_pending.push_back(0);
-        }
-    }
     e = hipMalloc(&h->rem_dev, sizeof(int32_t) * 3 * n_sub);
     if (e != hipSuccess) return fail((int)e);
     e = hipHostMalloc(&h->rem_host, sizeof(int32_t) * 3 * n_sub, hipHostMallocDefault);
@@ -169,9 +148,6 @@ void tm_search_destroy(tm_search* h) {
     if (!h) return;
     for (auto st : h->streams) if (st && h->own_streams) (void)hipStreamDestroy(st);
     for (auto e : h->ev_done) (void)hipEventDestroy(e);
-    for (auto ss : h->side) (void)hipStreamDestroy(ss);
-    for (auto e : h->ev_tree) (void)hipEventDestroy(e);
-    for (auto e : h->ev_side) (void)hipEventDestroy(e);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_loop0) (void)hipEventDestroy(h->ev_loop0);
@@ -202,28 +178,11 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
         h->sub[k].eval_parity ^= 1;      // the dense request list: every launch appends under the other parity (tm_store::eval_list)
         h->sub[k].game_list = owing > 0 ? h->owing_dev + h->first[k] : nullptr;
         h->sub[k].n_listed = owing;
-        // (the collector-only launch that ran beside the evaluator is complete before this launch's waves and collectors start:
-        // hand-overs between a game's wave and its collectors happen at kernel boundaries only)
-        if (!h->side.empty() && h->side_pending[k]) { TM_TRY(hipStreamWaitEvent(st[k], h->ev_side[k], 0)); h->side_pending[k] = 0; }
         // the evaluator is the built-in net, a function of the observation: only the requests whose outputs the backup uses
         const int e = tm_sim_step(&h->sub[k], TM_SIM_BACKUP | TM_SIM_FRONT | (vn_params ? TM_SIM_EVAL_NEEDED : 0), st[k]);
         h->sub[k].game_list = nullptr;
         h->sub[k].n_listed = 0;
-        if (e == 0 && !h->side.empty()) TM_TRY(hipEventRecord(h->ev_tree[k], st[k]));
         return e;
-    };
-    // beside the evaluator's kernels (they read packed observations and the request list, and write eval_v / eval_var: nothing a
-    // collection touches): the collector workgroups alone, a step of every collection under way, marking up to gc_side_cycles
-    auto gc_side = [&](int k) -> int {
-        if (h->side.empty() || h->sub[k].n_games == 0) return 0;
-        tm_store t = h->sub[k];
-        t.gc_slice_cycles = h->full.gc_side_cycles;
-        TM_TRY(hipStreamWaitEvent(h->side[k], h->ev_tree[k], 0));
-        TM_TRY(tm_gc_slice(&t, h->side[k]));
-        TM_TRY(hipEventRecord(h->ev_side[k], h->side[k]));
-        h->side_pending[k] = 1;
-        h->side_launches += 1;
-        return 0;
     };
     auto nn = [&](int k) -> int {
         if (!vn_params || h->sub[k].n_games == 0) return 0;
@@ -250,7 +209,6 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
                 h->ev_used += 3;
                 TM_TRY(hipEventRecord(e3[0], st[k]));
             }
-            TM_TRY(gc_side(k));
             TM_TRY(nn(k));
             if (e3) TM_TRY(hipEventRecord(e3[1], st[k]));
             TM_TRY(step(k));
@@ -284,7 +242,6 @@ int tm_search_run(tm_search* h, int sims, const float* vn_params, const float* v
         for (int i = 0; i < r; ++i)
             for (int k = 0; k < K; ++k)
                 if (h->rem_host[3 * k] > i) {
-                    TM_TRY(gc_side(k));
                     TM_TRY(nn(k));
                     TM_TRY(step(k, h->rem_host[3 * k + 2]));
                     h->extra_launches += 1;

@@ -2980,16 +2980,6 @@ int tm_gc_step(const tm_store* s, void* stream) {
         hipLaunchKernelGGL(k_sim_step<false>, grid, block, 0, (hipStream_t)stream, *s, flags);
     return TM_LAUNCH_CHECK();
 }
-int tm_gc_slice(const tm_store* s, void* stream) {
-    // the collector workgroups alone, with the launch's marking allowance: a step of every collection under way, beside the evaluator
-    const int flags = (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
-    const dim3 grid(gc_blocks(*s)), block(64 * WPB);
-    if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
-        hipLaunchKernelGGL(k_sim_step<true>, grid, block, WPB * sizeof(MtLds), (hipStream_t)stream, *s, flags);
-    else
-        hipLaunchKernelGGL(k_sim_step<false>, grid, block, 0, (hipStream_t)stream, *s, flags);
-    return TM_LAUNCH_CHECK();
-}
 int tm_move_begin(const tm_store* s, int sims, void* stream) {
     if (!s->eval_cnt) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_move_begin, dim3((s->n_games + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s, sims);

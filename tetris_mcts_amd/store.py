@@ -56,7 +56,7 @@ class TreeStore:
 
     def __init__(self, n_games, max_nodes=100000, kind=KIND_VALUESIM, env_args=((20, 10), 1, 0, 0), gamma=0.999,
                  low=1, eval_slots=None, max_trace=1024, nq_size=1 << 20, online=False, min_visits_to_store=10,
-                 replay_cap=0, gc_slice_cycles=150000, gc_spec_nodes=None, gc_cost_units=0, gc_collectors=0, gc_side_cycles=0, dist_bins=50, dist_range=(0.0, 5000.0), device="cuda"):
+                 replay_cap=0, gc_slice_cycles=150000, gc_spec_nodes=None, gc_cost_units=0, gc_collectors=0, dist_bins=50, dist_range=(0.0, 5000.0), device="cuda"):
         if not torch.cuda.is_available():
             raise RuntimeError("tetris_mcts_amd needs a ROCm GPU (gfx950); there is no CPU path")
         shape, app, scoring, randomizer = env_args[0], env_args[1], env_args[2], env_args[3]
@@ -116,7 +116,6 @@ class TreeStore:
                 setattr(s, name, self.t[name].data_ptr() if self.t[name] is not None else None)
         s.dist_bins, s.dist_vmin, s.dist_vmax = int(dist_bins), float(dist_range[0]), float(dist_range[1])
         s.eval_parity, s.eval_epoch, s.n_listed, s.gc_cost_units, s.gc_collectors = 0, 0, 0, int(gc_cost_units or 0), int(gc_collectors or 0)
-        s.gc_side_cycles = int(gc_side_cycles or 0)
         self.s = s
         self.stats_buf = torch.zeros(G, 3, 7, dtype=torch.float32, device=dev)
         self.action_buf = torch.zeros(G, dtype=torch.int32, device=dev)
