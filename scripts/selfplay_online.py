@@ -29,6 +29,8 @@ ap.add_argument("--min-visits", type=int, default=None, help="min_visits_to_stor
 ap.add_argument("--out", default="gpurun_out/online_learning.jsonl")
 ap.add_argument("--save", default=None, help="checkpoint file (the reference's format, model/model.py:152-160), written every --save-every rounds and at the end")
 ap.add_argument("--save-every", type=int, default=10)
+ap.add_argument("--load", default=None, help="start from this checkpoint instead of a random-init net")
+ap.add_argument("--no-train", action="store_true", help="play only (with --load: the checkpoint's play strength): no harvest, no fits")
 args = ap.parse_args()
 
 M.EXP_PATH = "/tmp/tm_ckpt/"
@@ -42,8 +44,11 @@ if args.agent.startswith("Dist"):
     model = Model_Dist(atoms=50, seed=0, backend="hip")
 else:
     model = M.Model_VV(backend="hip", seed=0)
+if args.load:
+    assert os.path.isfile(args.load), args.load
+    model.load(args.load, verbose=False)
 agent = getattr(agents, args.agent)(sims=args.sims, env=Tetris, env_args=env_args, n_games=G, max_nodes=args.max_nodes,
-                                    model=model, online=True, replay_cap=16384, **extra)
+                                    model=model, online=not args.no_train, replay_cap=0 if args.no_train else 16384, **extra)
 agent.update_root(game)
 t0 = t_round = time.time()
 moves, rounds = 0, 0
@@ -74,7 +79,7 @@ while time.time() - t0 < args.minutes * 60:
     if moves % args.train_every == 0:
         tuples = int(agent.store.t["replay_count"].sum().item())
         tt = time.time()
-        res = agent.train_nodes(iters_per_val=100, batch_size=1024, max_iters=args.train_iters, log=False)
+        res = None if args.no_train else agent.train_nodes(iters_per_val=100, batch_size=1024, max_iters=args.train_iters, log=False)
         rounds += 1
         rec = dict(round=rounds, t=round(time.time() - t0, 1), moves=moves, episodes=len(ep_lines),
                    mean_lines=float(np.mean(ep_lines)) if ep_lines else None,
