@@ -1,5 +1,6 @@
 #!/bin/bash
-# collector-only launches beside the evaluator (tm_store::gc_side_cycles): steady-state windows under both nets, side:slice pairs
+# collector-only launches beside the evaluator (an experiment: needs docs/experiments/r05_collectors_beside_the_evaluator.patch applied -
+# tm_store::gc_side_cycles, bench.py --gc-side-cycles): steady-state windows under both nets, side:slice pairs
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 cd $R
