@@ -340,7 +340,7 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx,
         }
     if args.online:
         out["exchange"] = {"what": "all-gather of the (packed observation, value, variance, visit) tuples harvested at GC, "
-                                   "once per move (tetris_mcts_amd/dist.py all_gather_tuples, backend nccl = RCCL)",
+                                   "once per move (tetris_mcts_amd/dist.py all_gather_tuples; `backend`: nccl = RCCL over xGMI, or gloo with --share-gpu)",
                            "backend": backend_name, "collective_ran": collective,
                            "calls": gather["calls"], "tuples": gather["tuples"], "bytes": gather["bytes"],
                            "ms_total": gather["ms"], "multiset_check": gather["checksum_ok"]}
