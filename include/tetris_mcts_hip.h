@@ -30,7 +30,7 @@ extern "C" {
 #define TM_REC_OBS 29      /* node_to_obs */
 #define TM_REC_SCORE 30    /* float32 score of the node's game */
 #define TM_REC_HDR 31      /* bits 0-2 number of unique children, bit 24 game ended, bit 25 expanded */
-#define TM_KIDS_DW 8       /* raw children row: child[7] in action order + pad */
+#define TM_KIDS_DW 8       /* raw children row: child[7] in action order + the node's observation */
 #define TM_GS_DW 64        /* per-game control block */
 #define TM_LEAF_DW 32      /* per-game leaf hand-off between the front and back halves of a simulation */
 #define TM_DIST_ROW 64       /* floats per row of node_dist / eval_dist (dist_bins <= 64 atoms, zero padded) */
@@ -67,10 +67,12 @@ enum {
                             observations; (launch << 4) | 7 complete (the game resumes in a later launch); speculative marking while the
                             game simulates: (launch << 4) | 8 requested, 9 under way, (launch << 4) | 10 the pool ran dry meanwhile */
     TM_GS_GC_ARRIVE,     /* collector workgroups that have done their share of the current step (bits 8..: some left work) */
-    TM_GS_GC_TAIL,       /* nodes discovered so far (queue length; device-scope atomic) */
-    TM_GS_GC_TAIL0,      /* the same as of the start of the launch */
-    TM_GS_GC_HEAD0,      /* every queue entry below this one has been processed */
-    TM_GS_GC_MINLEFT,    /* lowest queue position a collector workgroup left unprocessed in this launch (device-scope atomic min) */
+    TM_GS_GC_DIRTY0,     /* the marking's work list, bits 0-31: chunks of the index range (tree.hip gc_chunk_nodes) that hold marked nodes
+                            whose children have not been looked at (device-scope atomics: the marker takes and returns them, the
+                            write barrier of a speculative marking adds to them) */
+    TM_GS_GC_DIRTY1,     /* ... bits 32-63 */
+    TM_GS_GC_WORK,       /* speculative marking: chunks were flagged when the last launch that looked ended (the next one marks) */
+    TM_GS_GC_MARK_LAUNCHES, /* launches in which a collector workgroup marked for this game (all collections) */
     TM_GS_GC_SLICES,     /* launches in which collector workgroups worked on a collection of this game (all collections) */
     TM_GS_GC_RETRY,      /* the suspended expansion has already been through a collection */
     /* per-move simulation quota: tm_move_begin adds `sims` to the target; a launch starts a simulation for a game only
@@ -150,14 +152,15 @@ typedef struct tm_store {
     float *eval_v;        /* [G*eval_slots] evaluator outputs */
     float *eval_var;
     const float *nq_table;/* [nq_size] (float)norm_quantile(n), special.h:26-33, built on the host with libm */
-    uint8_t *gc_mark;     /* [G][2][N/8 rounded to 16B] scratch bitmaps for GC */
-    int32_t *gc_queue;    /* [G][N] BFS queue scratch */
+    uint8_t *gc_mark;     /* [G][2][N/8 rounded to 16B] scratch bitmaps for GC: reachable nodes, observations of reachable nodes */
+    int32_t *gc_queue;    /* [G][N] queue scratch of the one-group collection (update_root's exhausting pop, the single calls) */
     /* replay tuples harvested at GC (ValueSim.py:122-159): per game ring, gathered by the host side */
     uint32_t *replay_obs; /* [G][replay_cap][12] */
     float *replay_stat;   /* [G][replay_cap][4] value, variance, visit, 0 */
     int32_t *replay_count;/* [G] */
     uint32_t *mt_state;   /* [G][625] CPython random state per game (624 words + index), TM_KIND_VANILLA / TM_KIND_VANILLA_C rollouts (Vanilla.py:4,52) */
-    uint32_t *node_child; /* [G][N][8] raw child[7] per action (agents/agent.py:61) + pad */
+    uint32_t *node_child; /* [G][N][8] raw child[7] per action (agents/agent.py:61) + the node's own observation (node_to_obs once more:
+                             the collectors' marker reads children and observation in one 32-byte row) */
     int32_t *gc_part;     /* [G][TM_GC_PART_DW] per-collector counts of a collection in progress */
     /* TM_KIND_DIST only */
     float *node_dist;     /* [G][N][TM_DIST_ROW] the nodes' value distributions (agents/core_distributional.py node_dist) */

@@ -55,7 +55,8 @@ def lib():
         for name in ("root", "episode", "error", "n_avail", "n_obs_avail", "memory_index"):
             f = getattr(L, "orc_agent_" + name)
             f.restype, f.argtypes = i32, [vp]
-        for name in ("n_sims", "n_expand", "n_gc", "n_eval_states", "trace_len_sum", "max_trace_len", "n_eval_used", "n_eval_repeat"):
+        for name in ("n_sims", "n_expand", "n_gc", "n_eval_states", "trace_len_sum", "max_trace_len", "n_eval_used", "n_eval_repeat",
+                     "sweep_mismatch", "sweep_passes", "sweep_readings", "sweep_rows", "sweep_max_passes"):
             f = getattr(L, "orc_agent_" + name)
             f.restype, f.argtypes = C.c_long, [vp]
         L.orc_agent_set_mt.argtypes = [vp, vp]
@@ -87,6 +88,7 @@ def lib():
         L.orc_backup_trace_obs_LP.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, f64, i32, i32]
         L.orc_backup_obs_cppagent.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, f64, C.c_float]
         L.orc_get_all_childs.argtypes = [i32, vp, i32, vp]
+        L.orc_sweep_marks.argtypes = [i32, vp, i32, vp, i32, vp]
         L.orc_valuenet_forward.argtypes = [vp, vp, i32, vp, vp]
         L.orc_hash_eval.argtypes = [vp, vp, i32, vp, vp]
         L.orc_hash_dist.argtypes = [vp, vp, i32, i32, vp]
@@ -272,7 +274,8 @@ class Agent:
 
     def __getattr__(self, name):
         if name in ("root", "episode", "error", "n_avail", "n_obs_avail", "memory_index", "n_sims", "n_expand",
-                    "n_gc", "n_eval_states", "trace_len_sum", "max_trace_len", "n_rollout_steps", "n_eval_used", "n_eval_repeat"):
+                    "n_gc", "n_eval_states", "trace_len_sum", "max_trace_len", "n_rollout_steps", "n_eval_used", "n_eval_repeat",
+                    "sweep_mismatch", "sweep_passes", "sweep_readings", "sweep_rows", "sweep_max_passes"):
             return getattr(self.L, "orc_agent_" + name)(self.h)
         raise AttributeError(name)
 

@@ -267,3 +267,56 @@ int orc_get_all_childs(int index, const int32_t *child, int n_nodes, uint8_t *ma
     free(queue);
     return count;
 }
+
+/* The same set as orc_get_all_childs (core.h:32-50) by the SCHEDULE of the device's collector (tree.hip, gc_sweep_mark):
+ * no queue - two bitmaps, "marked" and "pending" (marked, children not looked at yet), and sweeps over the pending bitmap
+ * in DESCENDING index order (free indices are popped highest first, agents/agent.py:211-212 + deque.pop(): a node's
+ * children mostly lie below it, so one sweep carries a whole chain).  A sweep goes segment by segment (seg_nodes indices);
+ * a segment is re-read until it holds nothing pending; the nodes of one reading are processed TOGETHER (their child rows
+ * are loaded before any of their marks is set: the device's concurrency), so a mark made by a reading is seen by the
+ * next reading, never by its own.  A child above the segment under work is left for the next sweep, which starts at the
+ * highest such segment.  Node 0 is marked when a processed row holds a zero (the reference follows the zero entries of a
+ * row like any child, core.h:41-45) and never followed itself (its own row is all zero).  stats (may be NULL): [0] sweeps, [1] segment readings that found something,
+ * [2] child rows loaded (= nodes processed), [3] segment readings in all.  Returns the number of marked nodes. */
+int orc_sweep_marks(int index, const int32_t *child, int n_nodes, uint8_t *mark, int seg_nodes, long *stats) {
+    uint8_t *pend = (uint8_t *)calloc((size_t)n_nodes, 1);
+    int32_t *batch = (int32_t *)malloc(sizeof(int32_t) * (size_t)seg_nodes);
+    memset(mark, 0, (size_t)n_nodes);
+    const int n_seg = (n_nodes + seg_nodes - 1) / seg_nodes;
+    long sweeps = 0, readings_hit = 0, rows = 0, readings = 0;
+    int count = 1;
+    mark[index] = 1;
+    if (index != 0) pend[index] = 1;
+    int start = index / seg_nodes;                       /* highest segment that may hold something pending */
+    while (start >= 0) {
+        int next_start = -1;
+        sweeps += 1;
+        for (int s = start; s >= 0; --s) {
+            const int lo = s * seg_nodes, hi = lo + seg_nodes < n_nodes ? lo + seg_nodes : n_nodes;
+            for (;;) {
+                int nb = 0;
+                readings += 1;
+                for (int i = hi - 1; i >= lo; --i)
+                    if (pend[i]) { batch[nb++] = i; pend[i] = 0; }
+                if (nb == 0) break;
+                readings_hit += 1;
+                rows += nb;
+                for (int b = 0; b < nb; ++b)
+                    for (int a = 0; a < ORC_NACT; ++a) {
+                        const int c = child[(size_t)batch[b] * ORC_NACT + a];
+                        if (mark[c]) continue;
+                        mark[c] = 1; count += 1;
+                        if (c == 0) continue;
+                        pend[c] = 1;
+                        const int cs = c / seg_nodes;
+                        if (cs > s && cs > next_start) next_start = cs;
+                    }
+            }
+        }
+        start = next_start;
+    }
+    if (stats) { stats[0] = sweeps; stats[1] = readings_hit; stats[2] = rows; stats[3] = readings; }
+    (void)n_seg;
+    free(pend); free(batch);
+    return count;
+}

@@ -57,6 +57,8 @@ void orc_backup_obs_cppagent(const int32_t *trace, int len, int32_t *visit, floa
                              const float *_variance, double gamma, float leaf_score);
 /* core.h:32-50 ; mark[i]=1 for every reachable node (0 is always followed); returns count */
 int orc_get_all_childs(int index, const int32_t *child, int n_nodes, uint8_t *mark);
+/* the same set by the device collector's schedule (descending sweeps over a pending bitmap, tree.hip gc_sweep_mark) */
+int orc_sweep_marks(int index, const int32_t *child, int n_nodes, uint8_t *mark, int seg_nodes, long *stats);
 
 #ifdef __cplusplus
 }

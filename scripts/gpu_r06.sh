@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-6 GPU calls (one gpurun call each): scripts/gpu_r06.sh <part> [...]
+#   gc       smoke + the parity tests that go through collections (the sweep marker's gate), first failure stops
+#   steady   the steady-state windows (random-init and trained net), no CPU legs: ms/move, waiting launches, catch-up launches
+#   suite    the whole -m gpu suite as the driver runs it + smoke
+#   bench    the driver's command line
+OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
+CK=tetris_mcts_amd/checkpoints/value_net_online_r05.pt
+steady_line() { python - "$1" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for name, w in (("head", d), ("steady", d.get("steady_state"))):
+    if not w: continue
+    print(name, {k: w.get(k) for k in ("value", "ms_per_step", "gc", "tree_kernel_ms", "value_net_ms")})
+PY
+}
+cd $R
+for p in "$@"; do case $p in
+gc)
+  timeout 300 python __graft_entry__.py smoke > $OUT/r06.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $OUT/r06.smoke.log | cut -c1-300
+  ( time timeout 1500 python -m pytest -x -q -m gpu tests/test_gpu_tree.py tests/test_gpu_collector.py tests/test_gpu_benched_regime.py tests/test_gpu_dist_agent.py --durations=10 > $OUT/r06.gc_tests.log 2>&1 ) 2>&1 | grep real
+  tail -n 30 $OUT/r06.gc_tests.log | cut -c1-220 ;;
+steady)
+  timeout 600 python bench.py --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 > $OUT/r06.steady_random.json 2> $OUT/r06.steady_random.err; echo "random rc=$?"
+  steady_line $OUT/r06.steady_random.json
+  timeout 600 python bench.py --checkpoint $CK --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 > $OUT/r06.steady_trained.json 2> $OUT/r06.steady_trained.err; echo "trained rc=$?"
+  steady_line $OUT/r06.steady_trained.json ;;
+suite)
+  ( time timeout 1700 python -m pytest tests -m gpu -q --durations=15 > $OUT/r06.pytest.log 2>&1 ) 2>&1 | grep real
+  tail -n 24 $OUT/r06.pytest.log | cut -c1-200
+  timeout 300 python __graft_entry__.py smoke > $OUT/r06.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/r06.smoke.log | cut -c1-300 ;;
+bench)
+  ( time timeout 900 python bench.py > $OUT/r06.bench.json 2> $OUT/r06.bench.err ) 2>&1 | grep real
+  steady_line $OUT/r06.bench.json ;;
+esac; done

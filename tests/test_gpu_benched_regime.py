@@ -130,7 +130,8 @@ def test_traces_beyond_128_and_a_collection_at_the_full_pool(oracle):
     assert gs[0, 19] > 128, gs[0, 19]                 # TM_GS_MAX_TRACE: > 2 LDS flushes, 3 backup chunks
     assert gs[1, 9] >= 1                              # TM_GS_N_GC: the collection happened ...
     assert gs[1, 24] > 50000                          # ... with most of the pool reachable
-    assert gs[1, 38] > 5 * gs[1, 9]                   # TM_GS_GC_SLICES: ... over several launches (the steps of tree.hip)
+    assert gs[1, 38] >= 4 * gs[1, 9]                  # TM_GS_GC_SLICES: ... over several launches (the steps of tree.hip)
+    assert gs[1, 37] >= gs[1, 9]                      # TM_GS_GC_MARK_LAUNCHES: ... marked by the collector's sweep marker
     ss = agent.store.search_stats(1, 0)
     assert ss["catchup_launches"] > 0                 # the collecting game caught up after the regular launches
 

@@ -38,7 +38,29 @@ def test_agent_oracle_replays_reference(oracle, golden_dir, idx):
             a.update_root(g)
     if r["max_nodes"] < 100000:
         assert a.n_gc >= 1  # the fixture crosses at least one pool-exhaustion GC
+    assert a.sweep_mismatch == 0     # the device collector's marking schedule, run beside get_all_childs at every collection
     a.close()
+
+
+def test_sweep_marker_schedule_finds_the_reference_set_at_every_collection(oracle):
+    """oracle/uct_oracle.c orc_sweep_marks (the schedule of tree.hip's collector: descending sweeps over a pending bitmap)
+    against orc_get_all_childs (core.h:32-50, pinned on the reference's core.cpp) at every collection of long games with small
+    pools - trees that have been through many collections, where index order no longer follows allocation order."""
+    for kind, seed, pool in ((0, 5, 3000), (1, 6, 6000), (0, 7, 30000)):
+        g = oracle.Game(seed=seed)
+        a = oracle.Agent(kind, max_nodes=pool, evaluator="hash")
+        a.update_root(g)
+        for _ in range(400 if pool < 30000 else 150):
+            g.play(a.play(60 if pool < 30000 else 400))
+            a.update_root(g)
+            if g.end:
+                g.reset()
+                a.update_root(g)
+        assert a.n_gc >= (10 if pool < 30000 else 1), a.n_gc
+        assert a.sweep_mismatch == 0
+        # every reachable node's row is read once; a handful of sweeps, whatever the depth of the tree
+        assert a.sweep_max_passes <= 12, a.sweep_max_passes
+        a.close()
 
 
 def test_store_nodes_emits_replay_tuples(oracle):
@@ -75,7 +97,7 @@ def test_agent_oracle_replays_reference_cpp_agent(oracle, golden_dir, idx):
         if g.end:
             g.reset()
             a.update_root(g)
-    assert a.n_gc >= 1
+    assert a.n_gc >= 1 and a.sweep_mismatch == 0
     a.close()
 
 

@@ -263,6 +263,16 @@ __device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, u
 
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, int lane);
 
+// The collectors' marker (gc_sweep_mark below) works through the index range in blocks of GC_BLOCK_NODES nodes - GC_ROWS child
+// rows per thread of a 256-thread workgroup - and keeps its work list as 64 flags, one per CHUNK of the index range.
+constexpr int GC_ROWS = 4;
+constexpr int GC_BLOCK_NODES = GC_ROWS * 64 * WPB;
+__host__ __device__ inline int gc_chunk_nodes(int N) {
+    const int per = (N + 63) / 64;
+    return ((per + GC_BLOCK_NODES - 1) / GC_BLOCK_NODES) * GC_BLOCK_NODES;
+}
+__host__ __device__ inline size_t gc_bm_bytes(int N) { return (((size_t)N + 7) / 8 + 15) & ~(size_t)15; }
+
 constexpr int GC_REQ = 1, GC_DONE = 7;   // phase word: (launch << 4) | GC_REQ requested, 2..6 under way (GCP_*), (launch << 4) | GC_DONE complete
 // SPECULATIVE MARKING: a game that is about to run out of nodes (S.gc_spec_nodes left) has its tree marked while it goes
 // on simulating - the marking is what keeps a collecting game out for twenty launches.  Marks only ever grow while the
@@ -430,33 +440,32 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
         uint4* r = reinterpret_cast<uint4*>(P.rec() + (size_t)idx * TM_REC_DW);
         r[0] = z; r[1] = z; r[2] = z; r[3] = z; r[4] = z; r[5] = z; r[6] = z;
         r[7] = make_uint4(0u, (uint32_t)o, __float_as_uint((float)(int)my[14]), ((my[11] >> 8) & 1u) << 24);
+        // the raw child row: no children, and the node's observation once more (the collectors' marker reads both in one row)
         uint4* kd = reinterpret_cast<uint4*>(P.kids() + (size_t)idx * TM_KIDS_DW);
-        kd[0] = z; kd[1] = z;
+        kd[0] = z; kd[1] = make_uint4(0u, 0u, 0u, (uint32_t)o);
     }
     if (uniq && found) o = (int)P.rec()[(size_t)found * TM_REC_DW + TM_REC_OBS];
     if (barrier) {
         // write barrier of a speculative marking (see GC_SPEC_MARK): every successor about to be linked is marked; a new
-        // node with its observation (the marker never visits it: it has no children yet), an existing one that was not
-        // marked goes to the marker's queue
-        const size_t bm_bytes = (((size_t)S.max_nodes + 7) / 8 + 15) & ~(size_t)15;
+        // node with its observation (the marker need not visit it: it has no children yet, and whatever is linked under it
+        // later in this marking goes through this barrier too), an existing one that was not marked yet is marked and the
+        // chunk of the index range it lies in is flagged for the marker (TM_GS_GC_DIRTY*)
+        const size_t bm_bytes = gc_bm_bytes(S.max_nodes);
         uint32_t* nmw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes);
         uint32_t* omw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes + bm_bytes);
-        // Both kinds go into the queue (it lists the kept nodes for the table rebuild and the count): a new node as
-        // already processed (bit 31: it has no children), an existing one for the marker to visit.
-        bool shade = false, fresh = false;
+        bool shade = false;
         if (uniq && idx != 0) {
-            const uint32_t oldw = atomicOr(nmw + ((uint32_t)idx >> 5), 1u << (idx & 31));
-            fresh = !((oldw >> (idx & 31)) & 1u);
-            if (isnew) atomicOr(omw + ((uint32_t)o >> 5), 1u << (o & 31));
-            else shade = fresh;
+            if (isnew) {
+                atomicOr(nmw + ((uint32_t)idx >> 5), 1u << (idx & 31));
+                atomicOr(omw + ((uint32_t)o >> 5), 1u << (o & 31));
+            } else {
+                const uint32_t oldw = atomicOr(nmw + ((uint32_t)idx >> 5), 1u << (idx & 31));
+                shade = !((oldw >> (idx & 31)) & 1u);
+            }
         }
-        const uint64_t sm = __ballot(fresh), shm = __ballot(shade);
-        if (sm != 0ull) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&P.gs()[TM_GS_GC_TAIL], __popcll(sm));
-            base = (int)rl_u32((uint32_t)base, 0);
-            if (fresh) (S.gc_queue + (size_t)g * P.n())[base + __popcll(sm & ((1ull << lane) - 1ull))] = shade ? idx : (idx | (int)0x80000000);
-            if (lane == 0 && shm != 0ull) atomicMin(&P.gs()[TM_GS_GC_MINLEFT], base);
+        if (shade) {
+            const int ck = idx / gc_chunk_nodes(S.max_nodes);
+            atomicOr(&P.gs()[TM_GS_GC_DIRTY0 + (ck >> 5)], (int)(1u << (ck & 31)));
         }
     }
     {
@@ -1861,16 +1870,15 @@ __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, i
 // work, then ARRIVES (one device-scope atomic per game and workgroup); the last to arrive moves the game to the next
 // step.  The kernel boundary is the barrier between steps: nothing a workgroup writes is read by another in the same
 // launch, except through those atomics and the mark bitmaps (device-scope atomics as well).
-//   1 init    the bitmaps and the root by workgroup g % n, the two tables cleared by all
-//   2 mark    the queue holds every node discovered so far (bit 31 of an entry: its children have been marked); each
-//             workgroup takes its share of the entries that are not processed yet, marks their children (atomicOr: one
-//             workgroup sees a child first), appends what it discovers to the queue (atomic reservation) and goes on
-//             with its own discoveries until the launch's deadline; what it leaves is found by the next launch's scan.
-//             Complete when no workgroup left anything.
+//   1 init    the two tables cleared by the bounded workgroups - and the marking begun in the same launch by the game's
+//             marking workgroup (a speculative marking: only the bitmaps and the root, by workgroup g % n: the marking starts
+//             when the game's write barrier is up, one launch later)
+//   2 mark    ONE marking workgroup per game and launch, both bitmaps in its LDS: gc_sweep_mark below.  Complete when it
+//             leaves no chunk flagged.
 //   3 count   free nodes / free observations / harvested tuples per share of the index range
 //   4 write   ascending free lists (agents/agent.py:211-212,221-222), replay tuples in index order, freed statistics
 //             cleared - at the offsets the counts give
-//   5, 6      kept nodes, then kept observations, back into their tables (compare-and-swap)
+//   5, 6      kept nodes, then kept observations (the bitmaps say which), back into their tables (compare-and-swap)
 // All workgroups see the same games in the same steps: the control blocks they read were written in earlier launches.
 // A collection in progress must be continued by launches over the same range of games (same n).
 // ---------------------------------------------------------------------------------------------------
@@ -1878,19 +1886,26 @@ constexpr int GCP_INIT = GC_REQ, GCP_MARK = 2, GCP_COUNT = 3, GCP_WRITE = 4, GCP
 constexpr int GC_LIST_MAX = 256, GC_LIST_WAIT = 64;     // collecting games looked after per launch (the others wait): all, and those that are waiting for their collection
 constexpr int GC_COST_MAX = 12;      // per launch: cost units of the steps whose shares are done without looking at the clock
                                      // (init 1, count 1, write 2, nodes 5, observations 5: about 5 microseconds a unit)
-constexpr int GC_RING = 32;          // chunks of own discoveries a workgroup remembers while marking
-constexpr int GC_MARK_WGS_PER_GAME = 5;      // marking workgroups a marking game gets at most (r04's 32 marking workgroups over its ~7 marking games)
 struct GcLds {
     int scan[8];                     // Grp<256> scratch
     int n_list;
     int list_g[GC_LIST_MAX], list_ph[GC_LIST_MAX];       // the collecting games and their phase words as of the start of the launch
     int list_step[GC_LIST_MAX];                         // the launch's plan: the step performed for the game,
     short list_part[GC_LIST_MAX], list_parts[GC_LIST_MAX], list_share[GC_LIST_MAX];     // this workgroup's share (part of parts; parts 0: not in this launch)
+    unsigned char list_mark[GC_LIST_MAX];               // ... and whether this workgroup is the game's marker in this launch
     short order[GC_LIST_MAX]; int n_order;              // the games this workgroup works on, in order
+    short mk_list[GC_LIST_MAX];                         // the games that are marked in this launch, in the order of the plan
     int age[GC_LIST_WAIT]; short by_age[GC_LIST_WAIT];  // the waiting games: launches since the request, and sorted by that
     int hist[256];                                      // more than GC_LIST_WAIT games waiting: how many have waited how long
-    int ring_start[GC_RING], ring_cnt[GC_RING];
+    uint32_t dirty[2];                                  // the marker's work list: flagged chunks of the game under work
+    __attribute__((aligned(16))) uint32_t marks[1];     // (the two mark bitmaps of the game under work follow: gc_marks_in_lds)
 };
+static_assert(64 * WPB == 256, "GcLds::hist has one bin per thread of a collector workgroup");
+// k_sim_step's workgroups are five per CU (96 registers a wave): 160 KB / 5.  The marker keeps both bitmaps of the game it
+// marks in LDS when they fit beside GcLds (N <= 100 000: 2 x 12.5 KB); beyond that they stay in memory (same code, atomics).
+constexpr size_t GC_LDS_MAX = 32768 - 256;      // (256 bytes of static LDS come with the kernel: __syncthreads_or's)
+__host__ __device__ inline bool gc_marks_in_lds(int N) { return offsetof(GcLds, marks) + 2 * gc_bm_bytes(N) <= GC_LDS_MAX; }
+__host__ __device__ inline size_t gc_lds_bytes(int N) { return offsetof(GcLds, marks) + (gc_marks_in_lds(N) ? 2 * gc_bm_bytes(N) : 16); }
 
 // thread 0 of a workgroup, after the workgroup's stores for this game: returns true for the last workgroup to arrive
 __device__ __forceinline__ bool gc_arrive(int32_t* gs, int n_gc, bool leftover, bool& any_left, bool blocking) {
@@ -1903,6 +1918,163 @@ __device__ __forceinline__ bool gc_arrive(int32_t* gs, int n_gc, bool leftover, 
     return true;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// THE MARKER (core.h:32-50 get_all_childs, agents/agent.py:206-224 - the same set by another schedule; the schedule itself is
+// restated and checked against the reference's set in oracle/uct_oracle.c orc_sweep_marks).
+// The reference walks the tree breadth first; on the device that walk's duration is its DEPTH (40-80 levels of dependent round
+// trips, r03-r05: 17-30 launches per marking).  Reachability is a fixpoint, and where a node's children are does not depend on
+// what is marked: the child rows of a game are one contiguous array (32 B a node: seven children + the node's observation), and
+// free indices are popped highest first, so children mostly lie BELOW their parents.  So: ONE workgroup per marking game, both
+// mark bitmaps in its LDS, and sweeps over the index range in DESCENDING blocks of GC_BLOCK_NODES nodes:
+//   * a block's child rows are loaded - all of them, coalesced, whatever is marked: GC_ROWS rows a thread, in registers;
+//   * then the block is brought to ITS fixpoint in LDS: every marked node of the block that has not been looked at marks its
+//     children and its observation (a read, and an LDS atomic only where the bit is missing), a workgroup barrier, again until
+//     nothing in the block was newly marked - parents and children inside a block cost LDS round trips, not memory ones;
+//   * a child marked in ANOTHER block flags that block's chunk (64 flags over the index range, GcLds::dirty): below the block
+//     under work it is met later in this sweep, above it in the next sweep.  Only flagged chunks are loaded.
+// The marking is complete when no chunk is flagged.  It is resumable at block boundaries (the launch's deadline): marks go back
+// to the global bitmaps, flags to the game's control block (TM_GS_GC_DIRTY*), nothing else is kept.
+// Beside a simulating game (speculative marking) the game's write barrier ORs marks into the global bitmaps and flags chunks in
+// the control block while this runs: the marks are merged (atomicOr) instead of stored, the flags taken by exchange - a node
+// the barrier marks in this launch is seen by the next one.
+// Node 0 is marked when a processed row holds a zero (the reference follows zero entries like any child: every leaf's row) and
+// is never looked at itself (its own row is zero).
+// LDSM = false: pools whose bitmaps do not fit the LDS (gc_marks_in_lds) - the same sweeps with the marks in memory (device-scope
+// atomics and loads that bypass the first-level cache).  Correct, and not fast: no benchmarked configuration runs it.
+// ---------------------------------------------------------------------------------------------------
+template <bool LDSM>
+__device__ __forceinline__ bool gc_sweep_mark(const tm_store& S, const GP& P, GcLds& M, uint32_t* lds_marks, bool fresh, bool spec,
+                                              long long deadline, int tid, int* sm) {
+    constexpr int T = 64 * WPB, R = LDSM ? GC_ROWS : 1, BLOCK = R * T;      // (the form that is not fast is at least small)
+    typedef Grp<T> G_;
+    const int N = S.max_nodes;
+    int32_t* gs = P.gs();
+    const size_t bm_bytes = gc_bm_bytes(N);
+    const int nq = (int)(bm_bytes / 16);                 // 16-byte pieces of one bitmap
+    uint32_t* gnm = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)P.g * 2 * bm_bytes);
+    uint32_t* nm = LDSM ? lds_marks : gnm;
+    uint32_t* om = nm + bm_bytes / 4;                    // (the two bitmaps are contiguous in memory and in LDS)
+    const int bpc = gc_chunk_nodes(N) / BLOCK;                           // blocks per chunk
+    auto rd = [&](const uint32_t* p, uint32_t w) -> uint32_t {
+        if constexpr (LDSM) return p[w];
+        else return __hip_atomic_load(p + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // thread 0's clock for everybody - and a pair of barriers for everybody, deadline or not
+    auto over = [&]() { return G_::bcast((deadline >= 0 && (long long)__builtin_readcyclecounter() > deadline) ? 1 : 0, tid, sm) != 0; };
+    // ---- the marks so far, and the chunks that hold marked nodes nobody has looked at ----
+    {
+        uint4* m4 = reinterpret_cast<uint4*>(nm);
+        const uint4* g4 = reinterpret_cast<const uint4*>(gnm);
+        if (fresh) {
+            for (int i = tid; i < 2 * nq; i += T) m4[i] = make_uint4(0, 0, 0, 0);
+        } else if (LDSM) {
+            for (int i = tid; i < 2 * nq; i += T) m4[i] = g4[i];
+        }
+        if (!LDSM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t d0 = (uint32_t)atomicExch(&gs[TM_GS_GC_DIRTY0], 0), d1 = (uint32_t)atomicExch(&gs[TM_GS_GC_DIRTY1], 0);
+            if (fresh) {
+                const int root = gs[TM_GS_ROOT];
+                atomicOr(nm + (root >> 5), 1u << (root & 31));
+                const int ck = root / (bpc * BLOCK);
+                d0 = (root != 0 && ck < 32) ? 1u << ck : 0u;
+                d1 = (root != 0 && ck >= 32) ? 1u << (ck - 32) : 0u;
+            }
+            M.dirty[0] = d0; M.dirty[1] = d1;
+            gs[TM_GS_GC_MARK_LAUNCHES] += 1;
+        }
+        if (!LDSM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+    }
+    const uint4* kids4 = reinterpret_cast<const uint4*>(P.kids());
+    int cur = 64;                      // the sweep's position: chunks below it are still to come in this sweep
+    uint32_t zero_seen = 0;
+    for (;;) {
+        const uint64_t d = ((uint64_t)M.dirty[1] << 32) | M.dirty[0];       // (after a barrier: the same to every thread)
+        if (d == 0ull) break;
+        if (over()) break;
+        uint64_t below = cur >= 64 ? d : (d & ((1ull << cur) - 1ull));
+        if (below == 0ull) below = d;                                      // the next sweep: from the highest flagged chunk down
+        const int c = 63 - __clzll((long long)below);
+        cur = c;
+        if (tid == 0) atomicAnd(&M.dirty[c >> 5], ~(1u << (c & 31)));      // (everybody has read the flags: over()'s barriers)
+        for (int b = bpc - 1; b >= 0; --b) {
+            const int blk = c * bpc + b, base = blk * BLOCK;
+            if (base >= N) continue;
+            uint4 k0[R], k1[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int node = base + j * T + tid;
+                const bool ok = node < N;
+                k0[j] = ok ? kids4[(size_t)node * 2] : make_uint4(0, 0, 0, 0);
+                k1[j] = ok ? kids4[(size_t)node * 2 + 1] : make_uint4(0, 0, 0, 0);
+            }
+            __syncthreads();           // the flag of the chunk under work is down before anybody can raise it again
+            // (flags as integers and one level of branching: per-lane booleans live in scalar register pairs, and the 56 child
+            // bodies of a block would spill them)
+            uint32_t done = 0;
+            for (;;) {
+                uint32_t progress = 0;
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int node = base + j * T + tid;
+                    const uint32_t nw = rd(nm, (uint32_t)(node < N ? node : 0) >> 5);
+                    const uint32_t act = (node < N ? 1u : 0u) & ((nw >> (node & 31)) & 1u) & ~(done >> j);
+                    done |= act << j;
+                    progress |= act;
+                    const uint32_t ch[7] = {k0[j].x, k0[j].y, k0[j].z, k0[j].w, k1[j].x, k1[j].y, k1[j].z};
+#pragma unroll
+                    for (int a = 0; a < 7; ++a) {
+                        const uint32_t cn = act ? ch[a] : 0xFFFFFFFFu;      // (an idle lane reads word 0 and does nothing)
+                        zero_seen |= cn == 0u ? 1u : 0u;
+                        const uint32_t cw = cn + 1u > 1u ? cn >> 5 : 0u, bit = 1u << (cn & 31);
+                        if (cn + 1u > 1u && !(rd(nm, cw) & bit)) {
+                            atomicOr(nm + cw, bit);
+                            const int cb = (int)(cn / (uint32_t)BLOCK);
+                            const int cc = cb / bpc;
+                            // (this block's own loop meets a node of the block; a lower block of the chunk under work is still to come)
+                            if (cb != blk && !(cc == c && cb < blk)) atomicOr(&M.dirty[cc >> 5], 1u << (cc & 31));
+                        }
+                    }
+                    const uint32_t o = act ? k1[j].w : 0u;                   // the node's observation (0 in a slot that is being created)
+                    if (o != 0u && !(rd(om, o >> 5) & (1u << (o & 31)))) atomicOr(om + (o >> 5), 1u << (o & 31));
+                }
+                if (!LDSM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (!__syncthreads_or((int)progress)) break;
+            }
+        }
+    }
+    // ---- what is left, and the marks back where the other steps (and the next launch) read them ----
+    if (__syncthreads_or((int)zero_seen)) {
+        if (tid == 0) { atomicOr(nm, 1u); atomicOr(om, 1u); }
+        if (!LDSM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+    }
+    const uint32_t l0 = M.dirty[0], l1 = M.dirty[1];
+    const bool leftover = (l0 | l1) != 0u;
+    if (tid == 0 && leftover) { atomicOr(&gs[TM_GS_GC_DIRTY0], (int)l0); atomicOr(&gs[TM_GS_GC_DIRTY1], (int)l1); }
+    if (LDSM) {
+        const uint4* m4 = reinterpret_cast<const uint4*>(nm);
+        uint4* g4 = reinterpret_cast<uint4*>(gnm);
+        if (!spec) {
+            for (int i = tid; i < 2 * nq; i += T) g4[i] = m4[i];
+        } else {
+            // (the game's write barrier is setting bits in these words)
+            for (int i = tid; i < 2 * nq; i += T) {
+                const uint4 l = m4[i], g = g4[i];
+                if (l.x & ~g.x) atomicOr(gnm + 4 * i, l.x);
+                if (l.y & ~g.y) atomicOr(gnm + 4 * i + 1, l.y);
+                if (l.z & ~g.z) atomicOr(gnm + 4 * i + 2, l.z);
+                if (l.w & ~g.w) atomicOr(gnm + 4 * i + 3, l.w);
+            }
+        }
+    }
+    __syncthreads();                   // (the LDS bitmaps may be the next game's now)
+    return leftover;
+}
+
 __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags, int n_gc, GcLds& M) {
     constexpr int T = 64 * WPB;
     typedef Grp<T> G_;
@@ -1911,10 +2083,6 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
     const long long budget = ((flags & TM_SIM_GC_FULL) || S.gc_slice_cycles <= 0) ? -1 : (long long)S.gc_slice_cycles;
     const long long deadline = budget < 0 ? -1 : (long long)__builtin_readcyclecounter() + budget;
     int* sm = M.scan;
-    auto over = [&]() {
-        if (deadline < 0) return false;
-        return G_::bcast((long long)__builtin_readcyclecounter() > deadline ? 1 : 0, tid, sm) != 0;
-    };
     // ---- which games are collecting (requested in an earlier launch, or under way), in game order: first the games that
     // are waiting for their collection (at most GC_LIST_WAIT), then the speculative markings ----
     // thread t looks at a contiguous run of games (all its loads in flight together, one prefix sum for the whole list)
@@ -2031,7 +2199,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         __syncthreads();
     }
     const int N = S.max_nodes;
-    const size_t bm_bytes = (((size_t)N + 7) / 8 + 15) & ~(size_t)15;
+    const size_t bm_bytes = gc_bm_bytes(N);
     const uint32_t mask = (uint32_t)S.table_cap - 1u;
     const int n_words = (N + 31) / 32;
     const bool dharvest = S.online && S.replay_cap > 0 && S.kind == TM_KIND_DIST && S.replay_dist;
@@ -2039,21 +2207,23 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
     // THE LAUNCH'S PLAN (every workgroup derives the same one: the control words it reads were written in earlier launches,
     // or are written in this one only after every workgroup has arrived for the game).
     // The bounded steps first, as many as fit the launch's cost allowance - those of the waiting games oldest request first,
-    // then the speculative markings' starting at a game that rotates with the launch number; then the marking.  It is a breadth-first walk whose depth,
-    // not its size, sets its duration (a round trip per level, a hundred levels and more), so the games that are marking
-    // do not share the time but the WORKGROUPS: game j of the n_mark marking games is looked after by the marking
-    // workgroups cm with cm % n_mark == j.  Workgroups [0, n_b) do the bounded steps, [n_b, n_gc) the marking (a lone
-    // workgroup does both): a launch's bounded work must not take the marking's time, nor the other way round.
+    // then the speculative markings' starting at a game that rotates with the launch number; then the markings: ONE marking
+    // workgroup per game (gc_sweep_mark: the bitmaps of the game it marks live in its LDS), the games dealt round the marking
+    // workgroups in the same order, a workgroup's time shared between its games when there are more games than workgroups.
+    // Workgroups [0, n_b) do the bounded steps, [n_b, n_gc) the marking (a lone workgroup does both): a launch's bounded work
+    // must not take the marking's time, nor the other way round.  A collection's FIRST step is both: the tables are cleared by
+    // the bounded workgroups while the game's marking workgroup begins the marking (init of a blocking request), or takes it
+    // to its end (GC_REQ_SPEC: the game has stopped, what its barrier flagged is all there).
     // EVERY workgroup arrives for every game whose step is performed, with or without a share of the work: nobody moves a
     // game on before everybody has read its control words.  Arrivals without a share are made first, one thread per game,
-    // all in flight together (a speculative marking with nothing known to be unprocessed - GC_IDLE - is nothing but that:
-    // the last arriver takes in what the game's barrier has appended).
+    // all in flight together (a speculative marking with nothing flagged - GC_IDLE - is nothing but that: the last arriver
+    // looks at the flags the game's barrier has raised meanwhile).
     const int n_b = n_gc >= 2 ? n_gc / 2 : 1, n_m = n_gc >= 2 ? n_gc - n_b : 1;
     if (tid < n_list) {
         const int ph = M.list_ph[tid] & 15;
         const int32_t* gsk = S.gs + (size_t)M.list_g[tid] * TM_GS_DW;
         int step = ph == GC_REQ_OVER ? GCP_INIT : ph;   // the step this launch performs for the game
-        if (ph == GC_SPEC_MARK) step = gsk[TM_GS_GC_HEAD0] < gsk[TM_GS_GC_TAIL0] ? GCP_MARK : GC_IDLE;
+        if (ph == GC_SPEC_MARK) step = gsk[TM_GS_GC_WORK] != 0 ? GCP_MARK : GC_IDLE;
         // a collection under way was begun by launches with n_gc collector workgroups - its shares, its counts per workgroup and
         // its arrival count are cut for that many.  Met by a launch with another number (another range of games: a sub-batch
         // here, the whole store there) it is left alone and the game is flagged: a misuse must raise, not corrupt free lists.
@@ -2062,6 +2232,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
             if (c == 0) atomicOr(&S.gs[(size_t)M.list_g[tid] * TM_GS_DW + TM_GS_ERR], TM_ERR_GC_GRID);
         }
         M.list_step[tid] = step;
+        M.list_mark[tid] = 0;
         if (tid < n_wait) M.age[tid] = (seq - gsk[TM_GS_GC_REQ_AT]) & 0x7FFFF;      // launches since the game asked (the launch number has 19 bits)
     }
     __syncthreads();
@@ -2073,52 +2244,43 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
     }
     __syncthreads();
     if (tid == 0) {
-        // the marking workgroups: one pool, or - when waiting games and speculative markings both have marking to do - a
-        // half each (a waiting game is the one that costs launches)
-        int cnt[2] = {0, 0};
-        for (int k = 0; k < n_list; ++k) cnt[k >= n_wait ? 1 : 0] += M.list_step[k] == GCP_MARK ? 1 : 0;
-        const bool split = cnt[0] > 0 && cnt[1] > 0 && n_m >= 2;
-        const int wgs[2] = {split ? n_m / 2 : n_m, split ? n_m - n_m / 2 : n_m}, off[2] = {0, split ? n_m / 2 : 0};
-        const int tot[2] = {split ? cnt[0] : cnt[0] + cnt[1], split ? cnt[1] : cnt[0] + cnt[1]};
-        int mark_j[2] = {0, 0};
-        int cost_left = deadline < 0 ? 1 << 20 : (S.gc_cost_units > 0 ? S.gc_cost_units : GC_COST_MAX), n_order = 0;      // (collector-only launches: nothing to hold up)
+        int cost_left = deadline < 0 ? 1 << 20 : (S.gc_cost_units > 0 ? S.gc_cost_units : GC_COST_MAX), n_order = 0, n_mk = 0;      // (collector-only launches: nothing to hold up)
         const int cm = n_gc >= 2 ? c - n_b : 0;           // index among the marking workgroups (< 0: not one of them)
-        for (int pass = 0; pass < 4; ++pass) {            // bounded steps of the waiting games, of the others; the markings likewise
-            const int cls = pass & 1, first = cls ? n_wait : 0, n = cls ? n_spec : n_wait;
+        for (int cls = 0; cls < 2; ++cls) {               // the waiting games, then the speculative markings
+            const int first = cls ? n_wait : 0, n = cls ? n_spec : n_wait;
             for (int i = 0; i < n; ++i) {
-                const int k = pass == 0 ? M.by_age[i] : first + (i + seq) % n;
+                const int k = cls == 0 ? M.by_age[i] : first + (i + seq) % n;
                 const int step = M.list_step[k];
-                if ((pass < 2) == (step == GCP_MARK)) continue;
-                int my_part = -1, n_parts = 1, share = 0;
+                int my_part = -1, n_parts = 1;
+                M.list_share[k] = 0;
                 if (step == GC_FOREIGN) { M.list_parts[k] = 0; continue; }      // nobody arrives
-                if (step == GC_IDLE) {
-                    // everybody just arrives
-                } else if (step != GCP_MARK) {
+                if (step != GC_IDLE && step != GCP_MARK) {                      // (GC_IDLE: everybody just arrives)
                     const int cost = step == GCP_WRITE ? 2 : (step == GCP_NODES || step == GCP_OBS) ? 5 : 1;      // init / clear / count: 1
                     if (cost > cost_left) { M.list_parts[k] = 0; continue; }      // not in this launch: nobody arrives
                     cost_left -= cost;
                     n_parts = n_b;
                     my_part = c < n_b ? c : -1;
-                } else {
-                    const int j = mark_j[split ? cls : 0]++, n_mark = tot[cls], n_w = wgs[cls], cx = cm - off[cls];
-                    const bool mine = cm >= 0 && cx >= 0 && cx < n_w;
-                    if (n_mark <= n_w) {
-                        n_parts = n_w / n_mark + (j < n_w % n_mark ? 1 : 0);
-                        my_part = (mine && cx % n_mark == j) ? cx / n_mark : -1;
-                        // ... at most GC_MARK_WGS_PER_GAME of them: a marking is a chain of dependent round trips that more
-                        // workgroups do not shorten beyond that, and every workgroup that marks to the launch's deadline takes
-                        // memory bandwidth from the simulation waves (with a few games marking - the random-init net's steady
-                        // state - the others stay idle; under the trained net's load all of them work)
-                        if (n_parts > GC_MARK_WGS_PER_GAME) { n_parts = GC_MARK_WGS_PER_GAME; if (my_part >= GC_MARK_WGS_PER_GAME) my_part = -1; }
-                    } else {
-                        // more games marking than workgroups: workgroup j % n_w takes the whole of game j, its time shared
-                        my_part = (mine && j % n_w == cx) ? 0 : -1;
-                        share = (n_mark - 1 - j) / n_w + 1;      // games this workgroup still has before it, this one included
-                    }
                 }
-                M.list_part[k] = my_part; M.list_parts[k] = n_parts; M.list_share[k] = share;
-                if (my_part >= 0) M.order[n_order++] = k;
+                M.list_part[k] = my_part; M.list_parts[k] = n_parts;
+                if (step == GCP_MARK || step == GCP_INIT || step == GC_REQ_SPEC) M.mk_list[n_mk++] = (short)k;
             }
+        }
+        // the marked games round the marking workgroups; `share` = the games this workgroup still has before it, this one included
+        for (int j = 0; j < n_mk; ++j) {
+            const int k = M.mk_list[j];
+            if (cm >= 0 && j % n_m == cm) { M.list_mark[k] = 1; M.list_share[k] = (short)((n_mk - 1 - j) / n_m + 1); }
+        }
+        // this workgroup's work, in order: bounded shares (waiting games by age, then the others), then its markings
+        for (int cls = 0; cls < 2; ++cls) {
+            const int first = cls ? n_wait : 0, n = cls ? n_spec : n_wait;
+            for (int i = 0; i < n; ++i) {
+                const int k = cls == 0 ? M.by_age[i] : first + (i + seq) % n;
+                if (M.list_parts[k] != 0 && M.list_part[k] >= 0) M.order[n_order++] = (short)k;
+            }
+        }
+        for (int j = 0; j < n_mk; ++j) {
+            const int k = M.mk_list[j];
+            if (M.list_mark[k] && M.list_part[k] < 0) M.order[n_order++] = (short)k;
         }
         M.n_order = n_order;
     }
@@ -2130,31 +2292,25 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         int32_t* gs = S.gs + (size_t)g * TM_GS_DW;
         bool any_left = false;
         if (!gc_arrive(gs, n_gc, leftover, any_left, !spec && step != GC_SPEC_REQ)) return;
-        if (step == GCP_INIT || step == GC_SPEC_REQ) {
+        if (step == GCP_INIT) {
             gs[TM_GS_GC_NGC] = n_gc;               // the collection is the work of launches with this many collector workgroups
-            atomicExch(&gs[TM_GS_GC_TAIL], 1);
-            atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF);
-            gs[TM_GS_GC_TAIL0] = 1;
-            gs[TM_GS_GC_HEAD0] = 0;
-            // (speculative: the game's wave may have turned its request into a blocking one in this very launch - then
-            // that stands, and the next launch initialises from scratch)
-            if (step == GCP_INIT) gs[TM_GS_GC_PHASE] = GCP_MARK;
-            else atomicCAS(&gs[TM_GS_GC_PHASE], word_seen, GC_SPEC_MARK);
+            gs[TM_GS_GC_PHASE] = any_left ? GCP_MARK : GCP_COUNT;
+        } else if (step == GC_SPEC_REQ) {
+            gs[TM_GS_GC_NGC] = n_gc;
+            gs[TM_GS_GC_WORK] = 1;
+            // (the game's wave may have turned its request into a blocking one in this very launch - then that stands, and the
+            // next launch initialises from scratch)
+            atomicCAS(&gs[TM_GS_GC_PHASE], word_seen, GC_SPEC_MARK);
         } else if (step == GC_REQ_SPEC) {
-            // the game has stopped: nothing is appended any more - take in what its last launches appended
-            const int tl = atomicAdd(&gs[TM_GS_GC_TAIL], 0);
-            const int ml = atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF);
-            gs[TM_GS_GC_HEAD0] = min(min(tl, ml), gs[TM_GS_GC_HEAD0]);
-            gs[TM_GS_GC_TAIL0] = tl;
-            gs[TM_GS_GC_PHASE] = GCP_MARK;
+            // the game has stopped: nothing is flagged any more, and its marker has just taken in what its last launches flagged
+            gs[TM_GS_GC_PHASE] = any_left ? GCP_MARK : GCP_COUNT;
         } else if (step == GCP_MARK || step == GC_IDLE) {
-            const int tl = atomicAdd(&gs[TM_GS_GC_TAIL], 0);
-            const int ml = atomicExch(&gs[TM_GS_GC_MINLEFT], 0x7FFFFFFF);
-            gs[TM_GS_GC_TAIL0] = tl;
-            gs[TM_GS_GC_HEAD0] = min(tl, ml);
-            // a speculative marking never ends by itself (the game may append to the queue after this point), and it does
-            // not touch the phase word (the game's wave may have put its blocking request there in this launch)
-            if (!spec && !any_left && ml == 0x7FFFFFFF) gs[TM_GS_GC_PHASE] = GCP_COUNT;
+            // a speculative marking never ends by itself (the game may flag chunks after this point), and it does not touch the
+            // phase word (the game's wave may have put its blocking request there in this launch)
+            // (what the marker left comes with its arrival; what the barrier has flagged meanwhile is read here - a flag raised after
+            // this is seen by the next launch's last arriver)
+            if (spec) gs[TM_GS_GC_WORK] = (any_left || (atomicOr(&gs[TM_GS_GC_DIRTY0], 0) | atomicOr(&gs[TM_GS_GC_DIRTY1], 0)) != 0) ? 1 : 0;
+            else if (!any_left) gs[TM_GS_GC_PHASE] = GCP_COUNT;
         } else if (step == GCP_COUNT) {
             gs[TM_GS_GC_PHASE] = GCP_WRITE;
         } else if (step == GCP_WRITE) {
@@ -2164,6 +2320,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
             for (int b = 0; b < n_b; ++b) { nf += part[3 * b]; of += part[3 * b + 1]; kf += part[3 * b + 2]; }
             gs[TM_GS_NFREE_NODE] = nf;
             gs[TM_GS_NFREE_OBS] = of;
+            gs[TM_GS_CYC_TAIL + 1] = N - nf;      // reachable nodes at the last GC
             if (harvest || dharvest) {
                 const int m0 = S.replay_count[g];
                 if (m0 + kf > S.replay_cap) gs[TM_GS_N_DROPPED] += m0 + kf - S.replay_cap;   // never silently (the reference keeps all up to memory_size)
@@ -2175,28 +2332,21 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         } else {      // GCP_OBS
             gs[TM_GS_N_GC] += 1;
             gs[TM_GS_GC_IN_MOVE] = 1;
-            gs[TM_GS_CYC_TAIL + 1] = gs[TM_GS_GC_TAIL0];      // reachable nodes at the last GC
             gs[TM_GS_GC_PHASE] = (seq << 4) | GC_DONE;
         }
     };
-    if (tid < n_list && M.list_parts[tid] != 0 && M.list_part[tid] < 0) arrive(tid, false);
+    if (tid < n_list && M.list_parts[tid] != 0 && M.list_part[tid] < 0 && !M.list_mark[tid]) arrive(tid, false);
+    const bool marks_in_lds = gc_marks_in_lds(N);
     for (int e = 0; e < M.n_order; ++e) {
         const int k = M.order[e];
         const int g = M.list_g[k], ph = M.list_step[k], my_part = M.list_part[k], n_parts = M.list_parts[k];
-        long long my_deadline = deadline;
-        if (M.list_share[k] > 0 && deadline >= 0) {
-            const long long t0_ = (long long)__builtin_readcyclecounter();     // thread 0's clock for everybody
-            const long long t = ((long long)G_::bcast((int)(t0_ >> 32), tid, sm) << 32) | (unsigned)G_::bcast((int)t0_, tid, sm);
-            my_deadline = t >= deadline ? deadline : t + (deadline - t) / M.list_share[k];
-        }
         const long long p0 = my_part < 0 ? 0 : my_part, p1 = my_part < 0 ? 0 : my_part + 1;      // share = [x * p0 / n_parts, x * p1 / n_parts)
         const GP P = game_ptrs(S, g);
         int32_t* gs = P.gs();
         uint32_t* nmw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes);
         uint32_t* omw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes + bm_bytes);
-        int32_t* queue = S.gc_queue + (size_t)g * N;
         int32_t* part = S.gc_part + (size_t)g * TM_GC_PART_DW;
-        bool leftover = false;
+        if (my_part < 0) continue;        // (a marking only: the second loop)
         if (ph == GCP_INIT || ph == GC_SPEC_REQ || ph == GC_REQ_SPEC) {
             if (ph != GC_SPEC_REQ) {          // the tables are cleared once the game has stopped (it looks things up in them)
                 uint4* nt4 = reinterpret_cast<uint4*>(P.ntab());
@@ -2205,108 +2355,18 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                 const long long n4 = S.table_cap / 2;
                 const int lo = (int)(n4 * p0 / n_parts), hi = (int)(n4 * p1 / n_parts);
                 for (int i = lo + tid; i < hi; i += T) { nt4[i] = z4; ot4[i] = z4; }
-            }
-            if (ph != GC_REQ_SPEC && my_part == g % n_parts) {      // (after a speculative marking the bitmaps and the queue stand)
+            } else if (my_part == g % n_parts) {
+                // a speculative marking begins with the next launch, when the game's write barrier is up: empty bitmaps, the
+                // root marked and its chunk flagged (a blocking request's marker starts from scratch in its own LDS, now)
                 for (size_t i = tid; i < 2 * bm_bytes / 4; i += T) nmw[i] = 0;      // both bitmaps
                 __syncthreads();
-                // breadth-first marking; index 0 is followed like any other child (core.h:41-45), so it stays occupied
-                if (tid == 0) { const int root = gs[TM_GS_ROOT]; queue[0] = root; nmw[root >> 5] = 1u << (root & 31); }
+                if (tid == 0) {
+                    const int root = gs[TM_GS_ROOT], ck = root / gc_chunk_nodes(N);
+                    nmw[root >> 5] = 1u << (root & 31);
+                    atomicExch(&gs[TM_GS_GC_DIRTY0], (root != 0 && ck < 32) ? (int)(1u << ck) : 0);
+                    atomicExch(&gs[TM_GS_GC_DIRTY1], (root != 0 && ck >= 32) ? (int)(1u << (ck - 32)) : 0);
+                }
             }
-        } else if (ph == GCP_MARK) {
-            constexpr int U = 4;
-            // the entries [head0, tail0) may hold unprocessed ones (everything below head0 is processed): the marking
-            // workgroups of this game share that range
-            const long long head0 = gs[TM_GS_GC_HEAD0], span0 = gs[TM_GS_GC_TAIL0] - head0;
-            int cur = (int)(head0 + span0 * p0 / n_parts), cur_end = (int)(head0 + span0 * p1 / n_parts);
-            int ring_h = 0, ring_n = 0;          // chunks of this workgroup's own discoveries still to be processed
-            int dropped_min = 0x7FFFFFFF;        // chunks that did not fit the ring: the next launch's scan finds their entries
-            auto over_my = [&]() {
-                if (my_deadline < 0) return false;
-                return G_::bcast((long long)__builtin_readcyclecounter() > my_deadline ? 1 : 0, tid, sm) != 0;
-            };
-            bool timeup = over_my();
-            while (!timeup) {
-                if (cur >= cur_end) {
-                    if (ring_n == 0) break;
-                    cur = M.ring_start[ring_h]; cur_end = cur + M.ring_cnt[ring_h];
-                    ring_h = (ring_h + 1) % GC_RING; ring_n -= 1;
-                }
-                const int stop = min(cur_end, cur + T * U);
-                uint32_t ch[U][7];
-                uint32_t ob[U];
-                bool val[U];
-                int ent[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = cur + u * T + tid;
-                    ent[u] = i < stop ? queue[i] : -1;
-                    val[u] = ent[u] >= 0;                        // bit 31: already processed
-                }
-                if (!__syncthreads_or(val[0] || val[1] || val[2] || val[3])) {      // everything here was processed in an earlier launch
-                    cur = stop;
-                    timeup = over_my();
-                    continue;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = cur + u * T + tid;
-                    const int node = val[u] ? ent[u] : 0;
-                    const uint4 k0 = *reinterpret_cast<const uint4*>(P.kids() + (size_t)node * TM_KIDS_DW);
-                    const uint4 k1 = *reinterpret_cast<const uint4*>(P.kids() + (size_t)node * TM_KIDS_DW + 4);
-                    ob[u] = P.rec()[(size_t)node * TM_REC_DW + TM_REC_OBS];
-                    ch[u][0] = k0.x; ch[u][1] = k0.y; ch[u][2] = k0.z; ch[u][3] = k0.w; ch[u][4] = k1.x; ch[u][5] = k1.y; ch[u][6] = k1.z;
-                    if (val[u]) queue[i] = ent[u] | (int)0x80000000;
-                }
-                uint32_t fresh[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    // several actions of a node often lead to the same child (moves against a wall): one atomic per distinct child
-                    uint32_t skip = val[u] ? 0u : 0x7Fu;
-#pragma unroll
-                    for (int a = 1; a < 7; ++a)
-#pragma unroll
-                        for (int b = 0; b < a; ++b)
-                            if (ch[u][a] == ch[u][b]) skip |= 1u << a;
-                    uint32_t old[7];
-#pragma unroll
-                    for (int a = 0; a < 7; ++a)
-                        old[a] = ((skip >> a) & 1u) ? 0xFFFFFFFFu : atomicOr(nmw + (ch[u][a] >> 5), 1u << (ch[u][a] & 31));
-                    if (val[u]) atomicOr(omw + (ob[u] >> 5), 1u << (ob[u] & 31));
-                    uint32_t f = 0;
-#pragma unroll
-                    for (int a = 0; a < 7; ++a)
-                        if (!((old[a] >> (ch[u][a] & 31)) & 1u)) f |= 1u << a;
-                    fresh[u] = f;
-                }
-                int cnt = 0;
-#pragma unroll
-                for (int u = 0; u < U; ++u) cnt += __popc(fresh[u]);
-                int total;
-                int off = G_::exscan(cnt, tid, sm, total);
-                int qbase = 0;
-                if (total > 0) {
-                    qbase = G_::bcast(tid == 0 ? atomicAdd(&gs[TM_GS_GC_TAIL], total) : 0, tid, sm);
-                    off += qbase;
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-#pragma unroll
-                        for (int a = 0; a < 7; ++a)
-                            if ((fresh[u] >> a) & 1u) queue[off++] = (int)ch[u][a];
-                    if (ring_n < GC_RING) {
-                        if (tid == 0) { const int s = (ring_h + ring_n) % GC_RING; M.ring_start[s] = qbase; M.ring_cnt[s] = total; }
-                        ring_n += 1;
-                    } else dropped_min = min(dropped_min, qbase);
-                }
-                cur = stop;
-                __syncthreads();          // the queue entries and the ring are this workgroup's own (same CU)
-                timeup = over_my();
-            }
-            // what this workgroup leaves unprocessed, and the lowest queue position of it (for the next launch's scan)
-            int min_left = dropped_min;
-            if (cur < cur_end) min_left = min(min_left, cur);
-            for (int r = 0; r < ring_n; ++r) min_left = min(min_left, M.ring_start[(ring_h + r) % GC_RING]);
-            leftover = min_left != 0x7FFFFFFF;
-            if (leftover && tid == 0) atomicMin(&gs[TM_GS_GC_MINLEFT], min_left);
         } else if (ph == GCP_COUNT) {
             const int lo = (int)((long long)n_words * p0 / n_parts), hi = (int)((long long)n_words * p1 / n_parts);
             const int low_obs = gs[TM_GS_LOW_OBS];
@@ -2408,35 +2468,33 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                 }
             }
         } else if (ph == GCP_NODES) {
+            // the kept nodes, by index (the bitmap says which), back into their (cleared) table: threads claim empty slots with a
+            // 64-bit compare-and-swap (no deletions happen concurrently, so linear probing stays consistent; placement order
+            // does not affect lookups)
             constexpr int UR = 2;
-            const long long tail = gs[TM_GS_GC_TAIL0];
-            {
-                const int lo = (int)(tail * p0 / n_parts), hi = (int)(tail * p1 / n_parts);
-                for (int base = lo; base < hi; base += T * UR) {
-                    uint4 key[UR][4];
-                    int idx[UR];
+            const int lo = (int)((long long)N * p0 / n_parts), hi = (int)((long long)N * p1 / n_parts);
+            for (int base = lo; base < hi; base += T * UR) {
+                uint4 key[UR][4];
+                bool kept[UR];
 #pragma unroll
-                    for (int u = 0; u < UR; ++u) {
-                        const int q = base + u * T + tid;
-                        idx[u] = (q < hi) ? (queue[q] & 0x7FFFFFFF) : 0;
-                    }
+                for (int u = 0; u < UR; ++u) {
+                    const int i = base + u * T + tid;
+                    kept[u] = i > 0 && i < hi && ((nmw[i >> 5] >> (i & 31)) & 1u);
+                    const uint4* src = reinterpret_cast<const uint4*>(P.game() + (size_t)(kept[u] ? i : 0) * GAME_DW);
 #pragma unroll
-                    for (int u = 0; u < UR; ++u) {
-                        const uint4* src = reinterpret_cast<const uint4*>(P.game() + (size_t)idx[u] * GAME_DW);
+                    for (int t = 0; t < 4; ++t) key[u][t] = src[t];
+                }
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) key[u][t] = src[t];
-                    }
+                for (int u = 0; u < UR; ++u) {
+                    if (!kept[u]) continue;
+                    const int i = base + u * T + tid;
+                    uint32_t kw[GAME_DW];
 #pragma unroll
-                    for (int u = 0; u < UR; ++u) {
-                        if (idx[u] == 0) continue;
-                        uint32_t kw[GAME_DW];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) { kw[4*t] = key[u][t].x; kw[4*t+1] = key[u][t].y; kw[4*t+2] = key[u][t].z; kw[4*t+3] = key[u][t].w; }
-                        const uint64_t h = hash_game(kw);
-                        uint32_t sl = (uint32_t)h & mask;
-                        const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)idx[u];
-                        while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.ntab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
-                    }
+                    for (int t = 0; t < 4; ++t) { kw[4*t] = key[u][t].x; kw[4*t+1] = key[u][t].y; kw[4*t+2] = key[u][t].z; kw[4*t+3] = key[u][t].w; }
+                    const uint64_t h = hash_game(kw);
+                    uint32_t sl = (uint32_t)h & mask;
+                    const unsigned long long ent = ((h >> 32) << 32) | (uint32_t)i;
+                    while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.ntab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
                 }
             }
         } else if (S.kind != TM_KIND_DIST) {    // GCP_OBS (no observation table without the projection)
@@ -2469,7 +2527,25 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                 }
             }
         }
-        // ---- arrive ----
+        // ---- arrive (a game this workgroup also marks for - a lone collector workgroup - arrives after the marking) ----
+        __syncthreads();
+        if (tid == 0 && !M.list_mark[k]) arrive(k, false);
+        __syncthreads();
+    }
+    // the markings of this workgroup (a loop of its own: what a bounded share keeps in registers is dead here)
+    for (int e = 0; e < M.n_order; ++e) {
+        const int k = M.order[e];
+        if (!M.list_mark[k]) continue;
+        const GP P = game_ptrs(S, M.list_g[k]);
+        long long my_deadline = deadline;
+        if (M.list_share[k] > 1 && deadline >= 0) {
+            const long long t0_ = (long long)__builtin_readcyclecounter();     // thread 0's clock for everybody
+            const long long t = ((long long)G_::bcast((int)(t0_ >> 32), tid, sm) << 32) | (unsigned)G_::bcast((int)t0_, tid, sm);
+            my_deadline = t >= deadline ? deadline : t + (deadline - t) / M.list_share[k];
+        }
+        const bool fresh = M.list_step[k] == GCP_INIT, spec = (M.list_ph[k] & 15) == GC_SPEC_MARK;
+        const bool leftover = marks_in_lds ? gc_sweep_mark<true>(S, P, M, M.marks, fresh, spec, my_deadline, tid, sm)
+                                           : gc_sweep_mark<false>(S, P, M, nullptr, fresh, spec, my_deadline, tid, sm);
         __syncthreads();
         if (tid == 0) arrive(k, leftover);
         __syncthreads();
@@ -2479,10 +2555,17 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
+// LDS of a k_sim_step workgroup: a simulation workgroup's four WaveLds (+ the four Mersenne twisters of the rollout kinds), or a
+// collector workgroup's GcLds + the two mark bitmaps of the game it marks - one dynamic block, sized for the larger of the two
+__host__ inline size_t sim_lds_bytes(const tm_store& S, bool vanilla) {
+    const size_t sim = WPB * sizeof(WaveLds) + (vanilla ? WPB * sizeof(MtLds) : 0), gc = gc_lds_bytes(S.max_nodes);
+    return (sim > gc ? sim : gc);
+}
 template <bool VANILLA>
-__global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags) {
-    __shared__ WaveLds lds[WPB];
-    extern __shared__ __attribute__((aligned(16))) MtLds mt_lds[];   // WPB entries, only in the VANILLA instantiation
+__global__ __launch_bounds__(64 * WPB, 5) void k_sim_step(tm_store S, int flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sim_lds[];
+    WaveLds* lds = reinterpret_cast<WaveLds*>(sim_lds);
+    MtLds* mt_lds = reinterpret_cast<MtLds*>(sim_lds + WPB * sizeof(WaveLds));   // WPB entries, only in the VANILLA instantiation
     // the wave index is uniform by construction: say so, and every per-game base pointer lives in scalar registers
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     // The first workgroups of the grid are collectors: each looks after the garbage collections of a range of games, in
@@ -2490,12 +2573,11 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_sim_step(tm_store S, int flags)
     // simulation workgroups - they are dispatched first and share the CUs with them (a k_sim_step wave needs 70 registers).
     const int n_gc = gc_blocks(S);
     if ((int)blockIdx.x < n_gc) {
-        static_assert(sizeof(WaveLds) * WPB >= sizeof(GcLds), "collector scratch");
         // the dense request list: this launch appends under S.eval_parity; the other set of counters (the list the evaluator
         // drew from before this launch) is cleared for the next one
         if (blockIdx.x == 0 && (flags & TM_SIM_FRONT) && (int)threadIdx.x < TM_EVAL_SEGS(S.n_games))
             S.eval_cnt[(size_t)threadIdx.x * 2 + (S.eval_parity ^ 1)] = 0;
-        gc_collector_block(S, flags, n_gc, *reinterpret_cast<GcLds*>(lds));
+        gc_collector_block(S, flags, n_gc, *reinterpret_cast<GcLds*>(sim_lds));
         return;
     }
     // simulation wave i takes game i, or - a launch over some of the games: the catch-up launches - game_list[i]
@@ -2569,6 +2651,9 @@ __global__ void k_sims_remaining(tm_store S, int32_t* out) {
         const int ph = gs[TM_GS_GC_PHASE] & 15;
         col = (ph != 0 && ph != GC_DONE && ph != GC_SPEC_REQ && ph != GC_SPEC_MARK) ? 1 : 0;
         r = (gs[TM_GS_SIM_TARGET] - gs[TM_GS_SIM_STARTED]) + (gs[TM_GS_PENDING] != 0 ? 1 : 0) + col;
+        // (a game whose collection these launches will not touch - TM_ERR_GC_GRID - never finishes: nobody waits for it,
+        // the caller finds the flag)
+        if (gs[TM_GS_ERR] & TM_ERR_GC_GRID) { r = 0; col = 0; }
     }
     for (int d = 32; d >= 1; d >>= 1) { r = max(r, __shfl_xor(r, d, 64)); col += __shfl_xor(col, d, 64); }
     if ((threadIdx.x & 63) == 0) { if (r > 0) atomicMax(out, r); if (col > 0) atomicAdd(out + 1, col); }
@@ -2965,9 +3050,9 @@ int tm_sim_step(const tm_store* s, int flags, void* stream) {
     const int n_waves = s->game_list ? s->n_listed : s->n_games;       // simulation waves; the collectors are those of all n_games
     const dim3 grid((n_waves + WPB - 1) / WPB + gc_blocks(*s)), block(64 * WPB);
     if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
-        hipLaunchKernelGGL(k_sim_step<true>, grid, block, WPB * sizeof(MtLds), (hipStream_t)stream, *s, flags);
+        hipLaunchKernelGGL(k_sim_step<true>, grid, block, sim_lds_bytes(*s, true), (hipStream_t)stream, *s, flags);
     else
-        hipLaunchKernelGGL(k_sim_step<false>, grid, block, 0, (hipStream_t)stream, *s, flags);
+        hipLaunchKernelGGL(k_sim_step<false>, grid, block, sim_lds_bytes(*s, false), (hipStream_t)stream, *s, flags);
     return TM_LAUNCH_CHECK();
 }
 int tm_gc_step(const tm_store* s, void* stream) {
@@ -2975,9 +3060,9 @@ int tm_gc_step(const tm_store* s, void* stream) {
     const int flags = TM_SIM_GC_FULL | (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
     const dim3 grid(gc_blocks(*s)), block(64 * WPB);
     if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
-        hipLaunchKernelGGL(k_sim_step<true>, grid, block, WPB * sizeof(MtLds), (hipStream_t)stream, *s, flags);
+        hipLaunchKernelGGL(k_sim_step<true>, grid, block, sim_lds_bytes(*s, true), (hipStream_t)stream, *s, flags);
     else
-        hipLaunchKernelGGL(k_sim_step<false>, grid, block, 0, (hipStream_t)stream, *s, flags);
+        hipLaunchKernelGGL(k_sim_step<false>, grid, block, sim_lds_bytes(*s, false), (hipStream_t)stream, *s, flags);
     return TM_LAUNCH_CHECK();
 }
 int tm_move_begin(const tm_store* s, int sims, void* stream) {
