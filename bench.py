@@ -166,7 +166,7 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx,
                 gather["checksum_ok"] &= bool(int(tot[1].item()) == int(ka.shape[0]) and int(tot[0].item()) == int(got.item()))
 
     CNT = ("N_EXPAND", "N_SIMS", "TRACE_SUM", "N_EVAL", "N_GC", "GC_SLICES", "N_DROPPED", "N_POOL_RESET", "PREFIX_SUM",
-           "N_EVAL_SKIP", "N_EVAL_CACHED")
+           "N_EVAL_SKIP", "N_EVAL_CACHED", "GC_MARK_LAUNCHES", "GC_BLOCKS", "GC_ITERS", "GC_MARK_CYC", "GC_MARK_PARTS", "GC_MARK_SHARED", "GC_CYC_LOAD", "GC_CYC_ROUNDS", "GC_CYC_WAVES", "GC_IDLE_TURNS")
 
     def counters():
         return {k: S.counter(k) for k in CNT}
@@ -198,7 +198,10 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx,
                             d["N_GC"], d["GC_SLICES"], d["N_DROPPED"], ss.get("catchup_launches", 0.0), d["N_POOL_RESET"],
                             ss.get("gc_launches", 0.0), d["PREFIX_SUM"], d["N_EVAL_SKIP"], d["N_EVAL_CACHED"],
                             tally["lines_all"], tally["game_moves"], float(sum(tally["ended_lines"]) + prev_lines.sum()),
-                            float(len(tally["ended_lines"]) + G), ss.get("catchup_waves", 0.0)], dtype=torch.float64, device=dev)
+                            float(len(tally["ended_lines"]) + G), ss.get("catchup_waves", 0.0),
+                            d["GC_MARK_LAUNCHES"], d["GC_BLOCKS"], d["GC_ITERS"], d["GC_MARK_CYC"], d["GC_MARK_PARTS"],
+                            d["GC_MARK_SHARED"], d["GC_CYC_LOAD"], d["GC_CYC_ROUNDS"], d["GC_CYC_WAVES"], d["GC_IDLE_TURNS"]],
+                           dtype=torch.float64, device=dev)
         if world > 1:
             tmax = tot[:1].clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -206,7 +209,7 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx,
             tot[0] = tmax[0]
         keys = ("elapsed", "n_exp", "n_sims", "tr_sum", "n_eval", "episodes", "lines", "err", "n_gc", "gc_slices", "dropped",
                 "catchup", "pool_resets", "gc_launches", "prefix_sum", "n_skip", "n_cached", "lines_all", "game_moves",
-                "lines_under_way_sum", "episodes_under_way", "catchup_waves")
+                "lines_under_way_sum", "episodes_under_way", "catchup_waves", "mark_launches", "mark_blocks", "mark_iters", "mark_cyc64", "mark_parts", "mark_shared", "mark_cyc_load", "mark_cyc_rounds", "mark_cyc_waves", "mark_idle_turns")
         r = dict(zip(keys, [float(x) for x in tot.cpu()]))
         r["ss"], r["steps"] = ss, n_steps
         return r
@@ -268,7 +271,23 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx,
                 # full launch's (the evaluator draws from the dense request list and shrinks with them)
                 "catchup_full_launch_equivalents_per_move": r["catchup_waves"] / float(G) / r["steps"] / world,
                 "collector_only_launches": int(r["gc_launches"]), "dropped_tuples": int(r["dropped"]),
-                "trees_restarted_pool_outgrown": int(r["pool_resets"])}
+                "trees_restarted_pool_outgrown": int(r["pool_resets"]),
+                # the marker (tree.hip gc_sweep_mark): launches in which a workgroup marked, per collection; blocks of child rows it
+                # loaded; rounds of block-local marking per block; shader kilocycles per marking launch
+                "marker": {"launches_per_collection": (r["mark_launches"] / r["n_gc"]) if r["n_gc"] else None,
+                           "blocks_per_collection": (r["mark_blocks"] / r["n_gc"]) if r["n_gc"] else None,
+                           "rounds_per_block": (r["mark_iters"] / r["mark_blocks"]) if r["mark_blocks"] else None,
+                           "kcycles_per_block": (r["mark_cyc64"] * 0.064 / r["mark_blocks"]) if r["mark_blocks"] else None,
+                           "kcycles_per_launch": (r["mark_cyc64"] * 0.064 / r["mark_launches"]) if r["mark_launches"] else None,
+                           # per marking launch of a game: the workgroups it had (each owns a share of its index range), and
+                           # the games its workgroup had (more games marking than marking workgroups: the time is shared)
+                           "workgroups_per_launch": (r["mark_parts"] / r["mark_launches"]) if r["mark_launches"] else None,
+                           "games_per_workgroup": (r["mark_shared"] / r["mark_launches"]) if r["mark_launches"] else None,
+                           # a wave's kilocycles per block: waiting for the rows, marking; and per collection all in all
+                           "wave_kcycles_per_block_rows": (r["mark_cyc_load"] * 0.064 / r["mark_blocks"]) if r["mark_blocks"] else None,
+                           "wave_kcycles_per_block_marking": (r["mark_cyc_rounds"] * 0.064 / r["mark_blocks"]) if r["mark_blocks"] else None,
+                           "wave_kcycles_per_collection": (r["mark_cyc_waves"] * 0.064 / r["n_gc"]) if r["n_gc"] else None,
+                           "idle_turns_per_block": (r["mark_idle_turns"] / r["mark_blocks"]) if r["mark_blocks"] else None}}
 
     def request_block(r):
         """what the leaf evaluator was asked for: requests posted to the net, and those the search did without because the

@@ -67,11 +67,8 @@ enum {
                             observations; (launch << 4) | 7 complete (the game resumes in a later launch); speculative marking while the
                             game simulates: (launch << 4) | 8 requested, 9 under way, (launch << 4) | 10 the pool ran dry meanwhile */
     TM_GS_GC_ARRIVE,     /* collector workgroups that have done their share of the current step (bits 8..: some left work) */
-    TM_GS_GC_DIRTY0,     /* the marking's work list, bits 0-31: chunks of the index range (tree.hip gc_chunk_nodes) that hold marked nodes
-                            whose children have not been looked at (device-scope atomics: the marker takes and returns them, the
-                            write barrier of a speculative marking adds to them) */
-    TM_GS_GC_DIRTY1,     /* ... bits 32-63 */
-    TM_GS_GC_WORK,       /* speculative marking: chunks were flagged when the last launch that looked ended (the next one marks) */
+    TM_GS_GC_RSV0, TM_GS_GC_RSV1, /* (unused) */
+    TM_GS_GC_WORK,       /* marking: chunks were flagged when the last launch that looked ended (the next one marks) */
     TM_GS_GC_MARK_LAUNCHES, /* launches in which a collector workgroup marked for this game (all collections) */
     TM_GS_GC_SLICES,     /* launches in which collector workgroups worked on a collection of this game (all collections) */
     TM_GS_GC_RETRY,      /* the suspended expansion has already been through a collection */
@@ -90,8 +87,22 @@ enum {
     TM_GS_N_EVAL_SKIP,   /* leaf-parallel kinds: unique children of expanded leaves whose evaluation the backup would discard
                             (observation already visited / finished) - not posted under TM_SIM_EVAL_NEEDED, counted always */
     TM_GS_N_EVAL_CACHED, /* TM_KIND_VALUESIM / TM_KIND_CPPAGENT under TM_SIM_EVAL_NEEDED: leaves answered from obs_eval */
-    TM_GS_GC_NGC         /* collector workgroups of the launch that began the collection under way (its shares are cut for that many) */
+    TM_GS_GC_NGC,        /* collector workgroups of the launch that began the collection under way (its shares are cut for that many) */
+    TM_GS_GC_BLOCKS,     /* the marker's work, all collections: blocks of child rows loaded (tree.hip GC_BLOCK_NODES nodes each), */
+    TM_GS_GC_ITERS,      /* ... rounds of its block-local marking (one workgroup barrier each), */
+    TM_GS_GC_MARK_CYC,   /* ... shader cycles / 64 it was at it (summed over its workgroups) */
+    TM_GS_GC_FLAGS       /* 4 words = 128 flags, the marking's work list: chunks of the index range (tree.hip gc_chunk_log2) that hold
+                            pending nodes - marked, children not looked at yet (device-scope atomics: a marking workgroup takes the
+                            flags of its share of the range and returns what it leaves, the other marking workgroups of the game and
+                            the write barrier of a speculative marking raise them) */
+    , TM_GS_GC_MARK_PARTS = 58, /* sum over the marking launches of the marking workgroups the game had (each owns a share of its range) */
+    TM_GS_GC_MARK_SHARED,      /* sum over the marking launches of the games its marking workgroup had in that launch (its time is shared) */
+    TM_GS_GC_CYC_LOAD,         /* the marker's waves, shader cycles / 64: waiting for a block's rows, */
+    TM_GS_GC_CYC_ROUNDS,       /* ... marking inside a block, */
+    TM_GS_GC_CYC_WAVES,        /* ... in their loop all in all (the rest: looking for work, waiting for it), */
+    TM_GS_GC_IDLE_TURNS        /* turns of that loop that found nothing flagged */
 };
+#define TM_GC_FLAG_WORDS 4
 /* error bits in TM_GS_ERR */
 #define TM_ERR_POOL 1      /* node pool exhausted even after reclaiming unreachable nodes */
 #define TM_ERR_TRACE 2     /* trace longer than max_trace */

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-6 GPU calls (one gpurun call each): scripts/gpu_r06.sh <part> [...]
 #   gc       smoke + the parity tests that go through collections (the sweep marker's gate), first failure stops
+#   gcq      the quick version of gc
 #   steady   the steady-state windows (random-init and trained net), no CPU legs: ms/move, waiting launches, catch-up launches
 #   suite    the whole -m gpu suite as the driver runs it + smoke
 #   bench    the driver's command line
@@ -21,6 +22,11 @@ gc)
   timeout 300 python __graft_entry__.py smoke > $OUT/r06.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $OUT/r06.smoke.log | cut -c1-300
   ( time timeout 1500 python -m pytest -x -q -m gpu tests/test_gpu_tree.py tests/test_gpu_collector.py tests/test_gpu_benched_regime.py tests/test_gpu_dist_agent.py --durations=10 > $OUT/r06.gc_tests.log 2>&1 ) 2>&1 | grep real
   tail -n 30 $OUT/r06.gc_tests.log | cut -c1-220 ;;
+gcq)
+  # the quick gate: smoke, the collector tests, the benched-regime tests that live on collections
+  timeout 300 python __graft_entry__.py smoke > $OUT/r06.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/r06.smoke.log | cut -c1-300
+  ( time timeout 900 python -m pytest -x -q -m gpu tests/test_gpu_collector.py tests/test_gpu_benched_regime.py -k "collector or waiting or grid or catch_up or steady_state or trained or full_pool or under_load" > $OUT/r06.gcq_tests.log 2>&1 ) 2>&1 | grep real
+  tail -n 6 $OUT/r06.gcq_tests.log | cut -c1-220 ;;
 steady)
   timeout 600 python bench.py --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 > $OUT/r06.steady_random.json 2> $OUT/r06.steady_random.err; echo "random rc=$?"
   steady_line $OUT/r06.steady_random.json

@@ -263,14 +263,20 @@ __device__ __forceinline__ void table_insert_seq(uint64_t* tab, uint32_t mask, u
 
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, int lane);
 
-// The collectors' marker (gc_sweep_mark below) works through the index range in blocks of GC_BLOCK_NODES nodes - GC_ROWS child
-// rows per thread of a 256-thread workgroup - and keeps its work list as 64 flags, one per CHUNK of the index range.
+// The collectors' marker (gc_sweep_mark below) works through the index range in BLOCKS of GC_BLOCK_NODES nodes - GC_ROWS child
+// rows per lane of ONE WAVE - and keeps the flags the marking workgroups of a game exchange, 128 of them in the game's control
+// block, per CHUNK of the index range (GC_CHUNK_MIN_LOG2 nodes or more: a power of two of blocks, a node's chunk is a shift).
 constexpr int GC_ROWS = 4;
-constexpr int GC_BLOCK_NODES = GC_ROWS * 64 * WPB;
-__host__ __device__ inline int gc_chunk_nodes(int N) {
-    const int per = (N + 63) / 64;
-    return ((per + GC_BLOCK_NODES - 1) / GC_BLOCK_NODES) * GC_BLOCK_NODES;
+constexpr int GC_BLOCK_LOG2 = 8;
+constexpr int GC_BLOCK_NODES = GC_ROWS * 64;
+static_assert((1 << GC_BLOCK_LOG2) == GC_BLOCK_NODES, "a block is 256 nodes");
+constexpr int GC_CHUNK_MIN_LOG2 = 10;
+__host__ __device__ inline int gc_chunk_log2(int N) {
+    int cl = GC_CHUNK_MIN_LOG2;
+    while (((long long)(32 * TM_GC_FLAG_WORDS) << cl) < N) ++cl;
+    return cl;
 }
+__host__ __device__ inline int gc_chunk_nodes(int N) { return 1 << gc_chunk_log2(N); }
 __host__ __device__ inline size_t gc_bm_bytes(int N) { return (((size_t)N + 7) / 8 + 15) & ~(size_t)15; }
 
 constexpr int GC_REQ = 1, GC_DONE = 7;   // phase word: (launch << 4) | GC_REQ requested, 2..6 under way (GCP_*), (launch << 4) | GC_DONE complete
@@ -446,26 +452,32 @@ __device__ __forceinline__ void wave_new_nodes(const tm_store& S, const GP& P, W
     }
     if (uniq && found) o = (int)P.rec()[(size_t)found * TM_REC_DW + TM_REC_OBS];
     if (barrier) {
-        // write barrier of a speculative marking (see GC_SPEC_MARK): every successor about to be linked is marked; a new
-        // node with its observation (the marker need not visit it: it has no children yet, and whatever is linked under it
-        // later in this marking goes through this barrier too), an existing one that was not marked yet is marked and the
-        // chunk of the index range it lies in is flagged for the marker (TM_GS_GC_DIRTY*)
+        // write barrier of a speculative marking (see GC_SPEC_MARK): every successor about to be linked is marked - a new
+        // node, with its observation (the markers need not look at it: it has no children yet, and whatever is linked under
+        // it later in this marking goes through this barrier too) - or handed to the markers
         const size_t bm_bytes = gc_bm_bytes(S.max_nodes);
         uint32_t* nmw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes);
         uint32_t* omw = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)g * 2 * bm_bytes + bm_bytes);
-        bool shade = false;
         if (uniq && idx != 0) {
+            const uint32_t w = (uint32_t)idx >> 5, bit = 1u << (idx & 31);
             if (isnew) {
-                atomicOr(nmw + ((uint32_t)idx >> 5), 1u << (idx & 31));
+                atomicOr(nmw + w, bit);
                 atomicOr(omw + ((uint32_t)o >> 5), 1u << (o & 31));
-            } else {
-                const uint32_t oldw = atomicOr(nmw + ((uint32_t)idx >> 5), 1u << (idx & 31));
-                shade = !((oldw >> (idx & 31)) & 1u);
+            } else if (!(__hip_atomic_load(nmw + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) {
+                // An existing node that is not marked (in the global bitmap: as of the last launch) is SENT to the owner of its
+                // share of the index range like a child in another marking workgroup's share: its bit in the game's pending
+                // bitmap, and - once that atomic has been performed (its value is back) - its chunk's flag.  An owner that sees
+                // the flag finds the bit; an owner that has marked the node itself meanwhile drops it.  The node's MARK is the
+                // owner's to set (a mark tells an owner "looked at, or pending with me"); what has been sent once is
+                // remembered in a bitmap of the barrier's own (behind the pending bitmap).
+                uint32_t* pdw = reinterpret_cast<uint32_t*>(S.gc_queue + (size_t)g * S.max_nodes);
+                const uint32_t oldb = atomicOr(pdw + bm_bytes / 4 + w, bit), oldp = atomicOr(pdw + w, bit);
+                asm volatile("" :: "v"(oldb), "v"(oldp) : "memory");
+                if (!(oldb & bit)) {
+                    const int ck = idx >> gc_chunk_log2(S.max_nodes);
+                    atomicOr(&P.gs()[TM_GS_GC_FLAGS + (ck >> 5)], (int)(1u << (ck & 31)));
+                }
             }
-        }
-        if (shade) {
-            const int ck = idx / gc_chunk_nodes(S.max_nodes);
-            atomicOr(&P.gs()[TM_GS_GC_DIRTY0 + (ck >> 5)], (int)(1u << (ck & 31)));
         }
     }
     {
@@ -1886,6 +1898,7 @@ constexpr int GCP_INIT = GC_REQ, GCP_MARK = 2, GCP_COUNT = 3, GCP_WRITE = 4, GCP
 constexpr int GC_LIST_MAX = 256, GC_LIST_WAIT = 64;     // collecting games looked after per launch (the others wait): all, and those that are waiting for their collection
 constexpr int GC_COST_MAX = 12;      // per launch: cost units of the steps whose shares are done without looking at the clock
                                      // (init 1, count 1, write 2, nodes 5, observations 5: about 5 microseconds a unit)
+constexpr int GC_WL_WORDS = 16;       // the marker's work list: 512 units (a unit = a block for pools up to 131 072 nodes)
 struct GcLds {
     int scan[8];                     // Grp<256> scratch
     int n_list;
@@ -1893,11 +1906,20 @@ struct GcLds {
     int list_step[GC_LIST_MAX];                         // the launch's plan: the step performed for the game,
     short list_part[GC_LIST_MAX], list_parts[GC_LIST_MAX], list_share[GC_LIST_MAX];     // this workgroup's share (part of parts; parts 0: not in this launch)
     unsigned char list_mark[GC_LIST_MAX];               // ... and whether this workgroup is the game's marker in this launch
-    short order[GC_LIST_MAX]; int n_order;              // the games this workgroup works on, in order
-    short mk_list[GC_LIST_MAX];                         // the games that are marked in this launch, in the order of the plan
+    unsigned char list_mpart[GC_LIST_MAX], list_mparts[GC_LIST_MAX];     // ... with which share of the game's index range (part of parts)
+    int n_order;
+    union {
+        int hist[256];                                  // (building the list) more than GC_LIST_WAIT games waiting: how many have waited how long
+        struct { short order[GC_LIST_MAX];              // (the plan) the games this workgroup works on, in order
+                 short mk_list[GC_LIST_MAX]; };         // the games that are marked in this launch, in the order of the plan
+    };
     int age[GC_LIST_WAIT]; short by_age[GC_LIST_WAIT];  // the waiting games: launches since the request, and sorted by that
-    int hist[256];                                      // more than GC_LIST_WAIT games waiting: how many have waited how long
-    uint32_t dirty[2];                                  // the marker's work list: flagged chunks of the game under work
+    uint32_t dirty[TM_GC_FLAG_WORDS];                   // chunk flags on their way between the control block and the work list
+    uint32_t rmask[TM_GC_FLAG_WORDS];                   // which chunks this workgroup's share of the game under work is
+    uint32_t fsend[WPB][TM_GC_FLAG_WORDS];              // per wave: chunks of other shares to which it has sent nodes
+    uint32_t wl[GC_WL_WORDS];                           // the marker's work list: flagged units (blocks) of the share
+    int busy, quit;                                     // waves of the workgroup that hold a unit; nothing will come any more
+    int zero;                                           // a row with a zero entry has been looked at (node 0 is reachable)
     __attribute__((aligned(16))) uint32_t marks[1];     // (the two mark bitmaps of the game under work follow: gc_marks_in_lds)
 };
 static_assert(64 * WPB == 256, "GcLds::hist has one bin per thread of a collector workgroup");
@@ -1906,6 +1928,8 @@ static_assert(64 * WPB == 256, "GcLds::hist has one bin per thread of a collecto
 constexpr size_t GC_LDS_MAX = 32768 - 256;      // (256 bytes of static LDS come with the kernel: __syncthreads_or's)
 __host__ __device__ inline bool gc_marks_in_lds(int N) { return offsetof(GcLds, marks) + 2 * gc_bm_bytes(N) <= GC_LDS_MAX; }
 __host__ __device__ inline size_t gc_lds_bytes(int N) { return offsetof(GcLds, marks) + (gc_marks_in_lds(N) ? 2 * gc_bm_bytes(N) : 16); }
+static_assert(offsetof(GcLds, marks) + 2 * 12512 <= GC_LDS_MAX, "the reference's pool (ValueSim.py:16: 100 000 nodes) is marked in LDS");
+constexpr int GC_MARK_WGS_MAX = 8;      // marking workgroups a game gets at most (each owns a share of its index range)
 
 // thread 0 of a workgroup, after the workgroup's stores for this game: returns true for the last workgroup to arrive
 __device__ __forceinline__ bool gc_arrive(int32_t* gs, int n_gc, bool leftover, bool& any_left, bool blocking) {
@@ -1920,159 +1944,326 @@ __device__ __forceinline__ bool gc_arrive(int32_t* gs, int n_gc, bool leftover, 
 
 
 // ---------------------------------------------------------------------------------------------------
-// THE MARKER (core.h:32-50 get_all_childs, agents/agent.py:206-224 - the same set by another schedule; the schedule itself is
+// THE MARKER (core.h:32-50 get_all_childs, agents/agent.py:206-224 - the same set by another schedule; the schedule's core is
 // restated and checked against the reference's set in oracle/uct_oracle.c orc_sweep_marks).
 // The reference walks the tree breadth first; on the device that walk's duration is its DEPTH (40-80 levels of dependent round
 // trips, r03-r05: 17-30 launches per marking).  Reachability is a fixpoint, and where a node's children are does not depend on
 // what is marked: the child rows of a game are one contiguous array (32 B a node: seven children + the node's observation), and
-// free indices are popped highest first, so children mostly lie BELOW their parents.  So: ONE workgroup per marking game, both
-// mark bitmaps in its LDS, and sweeps over the index range in DESCENDING blocks of GC_BLOCK_NODES nodes:
-//   * a block's child rows are loaded - all of them, coalesced, whatever is marked: GC_ROWS rows a thread, in registers;
-//   * then the block is brought to ITS fixpoint in LDS: every marked node of the block that has not been looked at marks its
-//     children and its observation (a read, and an LDS atomic only where the bit is missing), a workgroup barrier, again until
-//     nothing in the block was newly marked - parents and children inside a block cost LDS round trips, not memory ones;
-//   * a child marked in ANOTHER block flags that block's chunk (64 flags over the index range, GcLds::dirty): below the block
-//     under work it is met later in this sweep, above it in the next sweep.  Only flagged chunks are loaded.
-// The marking is complete when no chunk is flagged.  It is resumable at block boundaries (the launch's deadline): marks go back
-// to the global bitmaps, flags to the game's control block (TM_GS_GC_DIRTY*), nothing else is kept.
-// Beside a simulating game (speculative marking) the game's write barrier ORs marks into the global bitmaps and flags chunks in
-// the control block while this runs: the marks are merged (atomicOr) instead of stored, the flags taken by exchange - a node
-// the barrier marks in this launch is seen by the next one.
+// free indices are popped highest first, so children mostly lie BELOW their parents.  So the index range is cut into BLOCKS of
+// 256 nodes, a game's marking workgroups each OWN a contiguous share of it (whole chunks of 1024 nodes or more: the unit the
+// owners' flags in the control block speak of), and an owner keeps two bitmaps of its share in LDS - MARKED, and PENDING
+// (marked, children not looked at yet) - and a work list of flagged blocks.  Its four WAVES work on their own, each on the
+// highest flagged block below where it was last (descending sweeps), with no workgroup barrier between them - one wave's
+// memory round trip is the others' work:
+//   * the block's child rows are loaded - all of them, coalesced, whatever is pending: GC_ROWS rows a lane, in registers -
+//     together with the block's words of the game's GLOBAL pending bitmap (taken by exchange: what other owners, earlier
+//     launches and the game's write barrier have sent; a bit the owner has marked already is dropped);
+//   * then the block is brought to ITS fixpoint: every pending node of the block is taken off the pending bitmap and marks
+//     its children - one LDS atomic with return for a child of the owner's share (not marked before: pending now; of this
+//     block: another round; of another block: that block into the work list, for whichever wave comes first) - and its
+//     observation (a device atomic into the global bitmap, nothing comes back); again while a node OF THIS BLOCK became
+//     pending.  Parents and children inside a block cost LDS round trips, not memory ones; a node's row is looked at once;
+//   * a child in ANOTHER owner's share is SENT: its bit into the global pending bitmap, then - after s_waitcnt vmcnt(0), the
+//     write-through-then-flag hand-off of MI355X_MICROARCH.md - its chunk's flag in the game's control block (TM_GS_GC_FLAGS).
+//     Nothing comes back and nobody waits: an owner without flagged blocks polls its flags a few times, then leaves.
+// The marking is complete when a launch ends with no flag up and nothing left by anybody.  It is resumable at block boundaries
+// (the launch's deadline): marks go back to the global bitmap (a node that is still pending goes back pending, not marked),
+// pending bits to the global pending bitmap (the head of the game's gc_queue words), flags to the control block; nothing else
+// is kept, and the next launch may cut the shares differently.
+// Beside a simulating game (speculative marking) the game's write barrier is one more sender, and ORs the marks of the nodes it
+// creates into the global bitmaps while this runs: an owner merges its marks (atomicOr) instead of storing them.
 // Node 0 is marked when a processed row holds a zero (the reference follows zero entries like any child: every leaf's row) and
 // is never looked at itself (its own row is zero).
-// LDSM = false: pools whose bitmaps do not fit the LDS (gc_marks_in_lds) - the same sweeps with the marks in memory (device-scope
-// atomics and loads that bypass the first-level cache).  Correct, and not fast: no benchmarked configuration runs it.
+// LDSM = false: pools whose bitmaps do not fit the LDS (gc_marks_in_lds) - the same with all three bitmaps in memory (device-
+// scope atomics, loads that bypass the first-level cache, one row a lane).  Correct, and not fast: no benchmarked configuration
+// runs it.
 // ---------------------------------------------------------------------------------------------------
+constexpr int GC_IDLE_POLLS = 12;      // looks at its flags an owner without work takes before it leaves the launch
 template <bool LDSM>
-__device__ __forceinline__ bool gc_sweep_mark(const tm_store& S, const GP& P, GcLds& M, uint32_t* lds_marks, bool fresh, bool spec,
-                                              long long deadline, int tid, int* sm) {
-    constexpr int T = 64 * WPB, R = LDSM ? GC_ROWS : 1, BLOCK = R * T;      // (the form that is not fast is at least small)
-    typedef Grp<T> G_;
-    const int N = S.max_nodes;
+__device__ __forceinline__ bool gc_sweep_mark(const tm_store& S, const GP& P, GcLds& M, uint32_t* lds_marks, int part, int n_parts,
+                                              bool spec, long long deadline, int tid, int* sm) {
+    constexpr int T = 64 * WPB, R = LDSM ? GC_ROWS : 1, BLOCK_LOG2 = LDSM ? GC_BLOCK_LOG2 : 6, BLOCK = 1 << BLOCK_LOG2;
+    constexpr int FW = TM_GC_FLAG_WORDS;
+    static_assert(BLOCK == R * 64 && FW == 4, "a block is a wave's: R rows a lane");
+    const int N = S.max_nodes, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int32_t* gs = P.gs();
     const size_t bm_bytes = gc_bm_bytes(N);
-    const int nq = (int)(bm_bytes / 16);                 // 16-byte pieces of one bitmap
+    const int nw = (int)(bm_bytes / 4);                  // words of one bitmap
     uint32_t* gnm = reinterpret_cast<uint32_t*>(S.gc_mark + (size_t)P.g * 2 * bm_bytes);
+    uint32_t* gom = gnm + nw;
+    uint32_t* gpd = reinterpret_cast<uint32_t*>(S.gc_queue + (size_t)P.g * N);
     uint32_t* nm = LDSM ? lds_marks : gnm;
-    uint32_t* om = nm + bm_bytes / 4;                    // (the two bitmaps are contiguous in memory and in LDS)
-    const int bpc = gc_chunk_nodes(N) / BLOCK;                           // blocks per chunk
-    auto rd = [&](const uint32_t* p, uint32_t w) -> uint32_t {
-        if constexpr (LDSM) return p[w];
-        else return __hip_atomic_load(p + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t* pd = LDSM ? lds_marks + nw : gpd;
+    // chunks (the control block's flags), units (the work list's; a block, or - very large pools - a power of two of blocks)
+    const int clog = gc_chunk_log2(N);
+    int ulog = BLOCK_LOG2;
+    while (((N + (1 << ulog) - 1) >> ulog) > 32 * GC_WL_WORDS) ++ulog;
+    const int upc_log = clog - ulog, bpu_log = ulog - BLOCK_LOG2;
+    const int n_chunks = (N + (1 << clog) - 1) >> clog, n_units = (N + (1 << ulog) - 1) >> ulog;
+    // this owner's share: chunks [c_lo, c_hi), nodes [n_lo, n_hi), bitmap words [w_lo, w_hi)
+    const int c_lo = (int)((long long)n_chunks * part / n_parts), c_hi = (int)((long long)n_chunks * (part + 1) / n_parts);
+    const int n_lo = c_lo << clog, n_hi = min(N, c_hi << clog);
+    const int w_lo = n_lo >> 5, w_hi = (n_hi + 31) >> 5;
+    auto rd = [&](const uint32_t* p, uint32_t w) -> uint32_t {          // (a bitmap word that other waves are setting bits in)
+        return __hip_atomic_load(p + w, __ATOMIC_RELAXED, LDSM ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT);
     };
-    // thread 0's clock for everybody - and a pair of barriers for everybody, deadline or not
-    auto over = [&]() { return G_::bcast((deadline >= 0 && (long long)__builtin_readcyclecounter() > deadline) ? 1 : 0, tid, sm) != 0; };
-    // ---- the marks so far, and the chunks that hold marked nodes nobody has looked at ----
-    {
-        uint4* m4 = reinterpret_cast<uint4*>(nm);
-        const uint4* g4 = reinterpret_cast<const uint4*>(gnm);
-        if (fresh) {
-            for (int i = tid; i < 2 * nq; i += T) m4[i] = make_uint4(0, 0, 0, 0);
-        } else if (LDSM) {
-            for (int i = tid; i < 2 * nq; i += T) m4[i] = g4[i];
-        }
-        if (!LDSM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t d0 = (uint32_t)atomicExch(&gs[TM_GS_GC_DIRTY0], 0), d1 = (uint32_t)atomicExch(&gs[TM_GS_GC_DIRTY1], 0);
-            if (fresh) {
-                const int root = gs[TM_GS_ROOT];
-                atomicOr(nm + (root >> 5), 1u << (root & 31));
-                const int ck = root / (bpc * BLOCK);
-                d0 = (root != 0 && ck < 32) ? 1u << ck : 0u;
-                d1 = (root != 0 && ck >= 32) ? 1u << (ck - 32) : 0u;
+    auto lds_rd = [&](const void* p) -> int { return __hip_atomic_load(reinterpret_cast<const int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    // One word of the game's global pending bitmap (what other owners, earlier launches and the game's write barrier have sent to
+    // 32 nodes of this share), taken by exchange: a node this owner has marked already has been, or will be, looked at - the
+    // others are marked and pending now, and their block goes into the work list.
+    auto take_word = [&](int iw) {
+        if (LDSM) {
+            const uint32_t x = atomicExch(gpd + iw, 0u);
+            if (x) {
+                const uint32_t fresh = x & ~rd(nm, (uint32_t)iw);
+                atomicOr(nm + iw, x);
+                if (fresh) { atomicOr(pd + iw, fresh); const int u = (iw << 5) >> ulog; atomicOr(&M.wl[u >> 5], 1u << (u & 31)); }
             }
-            M.dirty[0] = d0; M.dirty[1] = d1;
-            gs[TM_GS_GC_MARK_LAUNCHES] += 1;
+        } else if (rd(pd, (uint32_t)iw)) {      // (in memory the pending bitmap is the global one: the bits are where they belong)
+            const int u = (iw << 5) >> ulog;
+            atomicOr(&M.wl[u >> 5], 1u << (u & 31));
         }
-        if (!LDSM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    };
+    // the flags of this share that are up in the control block come down there and wait in LDS (GcLds::dirty) for a wave to
+    // take the flagged chunk's words of the global pending bitmap (lanes 0..3 of one wave)
+    auto poll_flags = [&]() {
+        if (lane < FW) {
+            const uint32_t mk = M.rmask[lane];
+            const uint32_t got = mk ? (uint32_t)atomicAnd(&gs[TM_GS_GC_FLAGS + lane], (int)~mk) & mk : 0u;
+            if (got) atomicOr(&M.dirty[lane], got);
+        }
+    };
+    // ---- the marks of this share so far, and its blocks that hold pending nodes ----
+    {
+        if (LDSM) for (int i = w_lo + tid; i < w_hi; i += T) { nm[i] = gnm[i]; pd[i] = 0u; }
+        if (tid < FW) {
+            uint32_t mk = 0;
+            for (int b = 0; b < 32; ++b) { const int ck = tid * 32 + b; if (ck >= c_lo && ck < c_hi) mk |= 1u << b; }
+            M.rmask[tid] = mk;
+            M.dirty[tid] = mk ? (uint32_t)atomicAnd(&gs[TM_GS_GC_FLAGS + tid], (int)~mk) & mk : 0u;      // the share's flags that are up
+        }
+        if (tid < WPB * FW) M.fsend[tid / FW][tid % FW] = 0u;
+        if (tid < GC_WL_WORDS) M.wl[tid] = 0u;
+        if (tid < 3) {                 // busy, quit, zero (a zero made here: hoisted out of the games' loop it was the kernel's only spill)
+            int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+            (&M.busy)[tid] = z;
+        }
+        if (tid == 0) gs[TM_GS_GC_MARK_LAUNCHES] += part == 0 ? 1 : 0;
         __syncthreads();
     }
     const uint4* kids4 = reinterpret_cast<const uint4*>(P.kids());
-    int cur = 64;                      // the sweep's position: chunks below it are still to come in this sweep
-    uint32_t zero_seen = 0;
+    int cur = 32 * GC_WL_WORDS;        // this wave's position: units below it are still to come in its sweep
+    int n_blocks = 0, n_iters = 0, idle = 0, n_idle = 0;
+    long long cyc_load = 0, cyc_rounds = 0;
+    const long long t_begin = (long long)__builtin_readcyclecounter();
+    // ---- the waves, each on its own ----
     for (;;) {
-        const uint64_t d = ((uint64_t)M.dirty[1] << 32) | M.dirty[0];       // (after a barrier: the same to every thread)
-        if (d == 0ull) break;
-        if (over()) break;
-        uint64_t below = cur >= 64 ? d : (d & ((1ull << cur) - 1ull));
-        if (below == 0ull) below = d;                                      // the next sweep: from the highest flagged chunk down
-        const int c = 63 - __clzll((long long)below);
-        cur = c;
-        if (tid == 0) atomicAnd(&M.dirty[c >> 5], ~(1u << (c & 31)));      // (everybody has read the flags: over()'s barriers)
-        for (int b = bpc - 1; b >= 0; --b) {
-            const int blk = c * bpc + b, base = blk * BLOCK;
+        if (deadline >= 0 && (long long)__builtin_readcyclecounter() > deadline) break;
+        // (the count of waves at work is read BEFORE the lists: a wave that has left the count has flagged what it found)
+        const int busy0 = lds_rd(&M.busy);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // a chunk whose flag has come down from the control block: its words of the global pending bitmap, one a lane
+        {
+            const uint32_t df = lane < FW ? (uint32_t)lds_rd(&M.dirty[lane < FW ? lane : 0]) : 0u;
+            const uint64_t dm = __ballot(df != 0u);
+            if (dm) {
+                const int di = __ffsll((long long)dm) - 1;
+                const uint32_t dw = rl_u32(df, di);
+                const int ck = 32 * di + 31 - __clz((int)dw);
+                uint32_t oldd = 0;
+                if (lane == 0) { atomicAdd(&M.busy, 1); oldd = atomicAnd(&M.dirty[di], ~(1u << (ck & 31))); }
+                oldd = rl_u32(oldd, 0);
+                if ((oldd >> (ck & 31)) & 1u) {
+                    for (int w0 = lane; w0 < (1 << (clog - 5)); w0 += 64) { const int iw = (ck << (clog - 5)) + w0; if (iw < nw) take_word(iw); }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
+                if (lane == 0) atomicSub(&M.busy, 1);
+                continue;
+            }
+        }
+        const uint32_t v = lane < GC_WL_WORDS ? (uint32_t)lds_rd(&M.wl[lane < GC_WL_WORDS ? lane : 0]) : 0u;
+        const int lim = cur - 32 * lane;                                 // bits of word `lane` below the position
+        const uint32_t vb = lim >= 32 ? v : lim <= 0 ? 0u : (v & ((1u << lim) - 1u));
+        uint64_t mb = __ballot(vb != 0u);
+        uint32_t word;
+        int wi;
+        if (mb) { wi = 63 - __clzll((long long)mb); word = rl_u32(vb, wi); }
+        else {
+            mb = __ballot(v != 0u);                                       // the next sweep: from the highest flagged unit down
+            wi = mb ? 63 - __clzll((long long)mb) : 0;
+            word = mb ? rl_u32(v, wi) : 0u;
+        }
+        if (word == 0u) {
+            n_idle += 1;
+            // nothing flagged in this share.  Another wave of the workgroup may still flag something ...
+            if (busy0 != 0) { __builtin_amdgcn_s_sleep(4); continue; }
+            // ... or another owner, or the game's barrier (what the barrier flags is the next launch's when it is the only sender)
+            if (n_parts == 1) break;
+            if (lds_rd(&M.quit)) break;
+            if (wave == 0) {
+                if (++idle > GC_IDLE_POLLS) { if (lane == 0) atomicExch(&M.quit, 1); break; }
+                __builtin_amdgcn_s_sleep(32);
+                poll_flags();
+            } else __builtin_amdgcn_s_sleep(16);
+            continue;
+        }
+        const int u = 32 * wi + 31 - __clz((int)word);
+        // claim it (another wave may be faster)
+        uint32_t oldw = 0;
+        if (lane == 0) { atomicAdd(&M.busy, 1); oldw = atomicAnd(&M.wl[u >> 5], ~(1u << (u & 31))); }
+        oldw = rl_u32(oldw, 0);
+        if (!((oldw >> (u & 31)) & 1u)) { if (lane == 0) atomicSub(&M.busy, 1); continue; }
+        cur = u;
+        idle = 0;
+        for (int b = (1 << bpu_log) - 1; b >= 0; --b) {
+            const int blk = (u << bpu_log) + b, base = blk << BLOCK_LOG2;
             if (base >= N) continue;
+            n_blocks += 1;
+            const long long tb0 = (long long)__builtin_readcyclecounter();
             uint4 k0[R], k1[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const int node = base + j * T + tid;
+                const int node = base + j * 64 + lane;
                 const bool ok = node < N;
                 k0[j] = ok ? kids4[(size_t)node * 2] : make_uint4(0, 0, 0, 0);
                 k1[j] = ok ? kids4[(size_t)node * 2 + 1] : make_uint4(0, 0, 0, 0);
             }
-            __syncthreads();           // the flag of the chunk under work is down before anybody can raise it again
-            // (flags as integers and one level of branching: per-lane booleans live in scalar register pairs, and the 56 child
-            // bodies of a block would spill them)
-            uint32_t done = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long tb1 = (long long)__builtin_readcyclecounter();
+            cyc_load += tb1 - tb0;
             for (;;) {
-                uint32_t progress = 0;
+                uint32_t again = 0, zero_seen = 0;
+                n_iters += 1;
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    const int node = base + j * T + tid;
-                    const uint32_t nw = rd(nm, (uint32_t)(node < N ? node : 0) >> 5);
-                    const uint32_t act = (node < N ? 1u : 0u) & ((nw >> (node & 31)) & 1u) & ~(done >> j);
-                    done |= act << j;
-                    progress |= act;
-                    const uint32_t ch[7] = {k0[j].x, k0[j].y, k0[j].z, k0[j].w, k1[j].x, k1[j].y, k1[j].z};
-#pragma unroll
-                    for (int a = 0; a < 7; ++a) {
-                        const uint32_t cn = act ? ch[a] : 0xFFFFFFFFu;      // (an idle lane reads word 0 and does nothing)
-                        zero_seen |= cn == 0u ? 1u : 0u;
-                        const uint32_t cw = cn + 1u > 1u ? cn >> 5 : 0u, bit = 1u << (cn & 31);
-                        if (cn + 1u > 1u && !(rd(nm, cw) & bit)) {
-                            atomicOr(nm + cw, bit);
-                            const int cb = (int)(cn / (uint32_t)BLOCK);
-                            const int cc = cb / bpc;
-                            // (this block's own loop meets a node of the block; a lower block of the chunk under work is still to come)
-                            if (cb != blk && !(cc == c && cb < blk)) atomicOr(&M.dirty[cc >> 5], 1u << (cc & 31));
+                    const int node = base + j * 64 + lane;         // (the wave's lanes: 64 consecutive nodes = two words)
+                    const uint32_t pw = rd(pd, (uint32_t)(node < N ? node : 0) >> 5);
+                    const uint32_t pend = (node < N ? 1u : 0u) & (pw >> (node & 31)) & 1u;
+                    const uint64_t pm = __ballot((int)pend);
+                    if (pm == 0ull) continue;                      // (after the first round few slots have anything)
+                    if ((lane & 31) == 0) {
+                        const uint32_t half = lane ? (uint32_t)(pm >> 32) : (uint32_t)pm;
+                        if (half) atomicAnd(pd + ((uint32_t)node >> 5), ~half);
+                        if (!LDSM && half) atomicOr(nm + ((uint32_t)node >> 5), half);      // (in LDS: marked when it was taken)
+                    }
+                    // Most rows are a leaf's (all zero), and of a block's nodes few are pending at a time: the children are not marked
+                    // seven a lane, but EIGHT PENDING EXPANDED NODES AT A TIME, one child a lane (lane l: child l & 7 of the group's
+                    // node l >> 3; 56 of the 64 lanes) - the instructions a block costs are what bounds the marker (a wave's
+                    // round trip for the rows: 1 300 cycles; the marking of a block with seven children a lane: 12 000).
+                    const bool expd = pend && (k0[j].x | k0[j].y | k0[j].z | k0[j].w | k1[j].x | k1[j].y | k1[j].z) != 0u;
+                    zero_seen |= (pend && !expd) ? 1u : 0u;                  // (a leaf: its row's zeros reach node 0)
+                    const uint64_t em = __ballot(expd);
+                    if (em != 0ull) {
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                        const int n_exp = __popcll(em);
+                        // lane r gets the lane of the node of rank r (the lanes that have nothing to push push to lane 63, which is
+                        // read only when all 64 have): one push for the slot, a pull a group
+                        const int ranked = __builtin_amdgcn_ds_permute((expd ? rank : 63) << 2, lane);
+                        const int a = lane & 7;
+                        // one child a lane out of the rows of the group's eight nodes
+                        auto gather = [&](int g) -> uint32_t {
+                            const int src = __builtin_amdgcn_ds_bpermute((8 * g + (lane >> 3)) << 2, ranked) << 2;
+                            uint32_t cn = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)k0[j].x);
+                            { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)k0[j].y); cn = a == 1 ? t : cn; }
+                            { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)k0[j].z); cn = a == 2 ? t : cn; }
+                            { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)k0[j].w); cn = a == 3 ? t : cn; }
+                            { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)k1[j].x); cn = a == 4 ? t : cn; }
+                            { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)k1[j].y); cn = a == 5 ? t : cn; }
+                            { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)k1[j].z); cn = a == 6 ? t : cn; }
+                            const bool valid = 8 * g + (lane >> 3) < n_exp && a < 7;
+                            zero_seen |= (valid && cn == 0u) ? 1u : 0u;
+                            return valid ? cn : 0u;
+                        };
+                        auto is_own = [&](uint32_t cn) { return cn != 0u && (LDSM ? ((int)cn >= n_lo && (int)cn < n_hi) : true); };
+                        // what a test-and-set found
+                        auto settle = [&](uint32_t cn, uint32_t old) {
+                            if (cn == 0u) return;
+                            const uint32_t bit = 1u << (cn & 31);
+                            const int cb = (int)(cn >> BLOCK_LOG2), cu = cb >> bpu_log, cc = (int)(cn >> clog);
+                            const bool own = is_own(cn);
+                            bool flag_other = !own;
+                            if (own && !(old & bit)) {
+                                atomicOr(pd + (cn >> 5), bit);
+                                // this block's own next round meets a node of the block; a lower block of the unit under work is
+                                // still to come; every other block of this share: into the work list
+                                if (cb == blk) again = 1;
+                                else if (!(cu == u && cb < blk)) {
+                                    if (LDSM || ((M.rmask[cc >> 5] >> (cc & 31)) & 1u)) atomicOr(&M.wl[cu >> 5], 1u << (cu & 31));
+                                    else flag_other = true;
+                                }
+                            } else if (!own) atomicOr(gpd + (cn >> 5), bit);        // sent: the owner of that share takes it from there
+                            // another owner's chunk: its flag goes up in the control block once the pending bit is in memory
+                            if (flag_other) atomicOr(&M.fsend[wave][cc >> 5], 1u << (cc & 31));
+                        };
+                        // two groups a turn: their LDS round trips (pull, gather, test-and-set: a group is a chain of them) overlap
+                        for (int g = 0; 8 * g < n_exp; g += 2) {
+                            const uint32_t ca = gather(g), cb2 = gather(g + 1);
+                            uint32_t oa = 0xFFFFFFFFu, ob = 0xFFFFFFFFu;
+                            if (is_own(ca)) oa = atomicOr(nm + (ca >> 5), 1u << (ca & 31));        // (only the lanes that have one: LDS atomics of
+                            if (is_own(cb2)) ob = atomicOr(nm + (cb2 >> 5), 1u << (cb2 & 31));    //  many lanes on one address are serialised)
+                            settle(ca, oa);
+                            settle(cb2, ob);
                         }
                     }
-                    const uint32_t o = act ? k1[j].w : 0u;                   // the node's observation (0 in a slot that is being created)
-                    if (o != 0u && !(rd(om, o >> 5) & (1u << (o & 31)))) atomicOr(om + (o >> 5), 1u << (o & 31));
+                    const uint32_t o = pend ? k1[j].w : 0u;                  // the node's observation (0 in a slot that is being created)
+                    if (o != 0u) atomicOr(gom + (o >> 5), 1u << (o & 31));
                 }
+                if (__any((int)zero_seen) && lane == 0) atomicExch(&M.zero, 1);
                 if (!LDSM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (!__syncthreads_or((int)progress)) break;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (!__any((int)again)) break;
+            }
+            cyc_rounds += (long long)__builtin_readcyclecounter() - tb1;
+        }
+        // the flags of other owners' chunks: up in the control block once every pending bit this wave sent is in memory
+        {
+            const uint32_t f = lane < FW ? (uint32_t)lds_rd(&M.fsend[wave][lane < FW ? lane : 0]) : 0u;
+            if (__any(f != 0u)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (f) { atomicAnd(&M.fsend[wave][lane], ~f); atomicOr(&gs[TM_GS_GC_FLAGS + lane], (int)f); }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // (what this wave flagged is in the work list before it leaves the count)
+        if (lane == 0) atomicSub(&M.busy, 1);
     }
     // ---- what is left, and the marks back where the other steps (and the next launch) read them ----
-    if (__syncthreads_or((int)zero_seen)) {
-        if (tid == 0) { atomicOr(nm, 1u); atomicOr(om, 1u); }
-        if (!LDSM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-    }
-    const uint32_t l0 = M.dirty[0], l1 = M.dirty[1];
-    const bool leftover = (l0 | l1) != 0u;
-    if (tid == 0 && leftover) { atomicOr(&gs[TM_GS_GC_DIRTY0], (int)l0); atomicOr(&gs[TM_GS_GC_DIRTY1], (int)l1); }
-    if (LDSM) {
-        const uint4* m4 = reinterpret_cast<const uint4*>(nm);
-        uint4* g4 = reinterpret_cast<uint4*>(gnm);
-        if (!spec) {
-            for (int i = tid; i < 2 * nq; i += T) g4[i] = m4[i];
-        } else {
-            // (the game's write barrier is setting bits in these words)
-            for (int i = tid; i < 2 * nq; i += T) {
-                const uint4 l = m4[i], g = g4[i];
-                if (l.x & ~g.x) atomicOr(gnm + 4 * i, l.x);
-                if (l.y & ~g.y) atomicOr(gnm + 4 * i + 1, l.y);
-                if (l.z & ~g.z) atomicOr(gnm + 4 * i + 2, l.z);
-                if (l.w & ~g.w) atomicOr(gnm + 4 * i + 3, l.w);
-            }
+    __syncthreads();
+    if (tid == 0 && M.zero) { atomicOr(gnm, 1u); atomicOr(gom, 1u); }     // (word 0 of the global bitmap, whoever owns it)
+    if (tid < GC_WL_WORDS) {           // the work list's units back into chunk flags
+        for (uint32_t left = M.wl[tid]; left; left &= left - 1) {
+            const int ck = (32 * tid + __ffs((int)left) - 1) >> upc_log;
+            atomicOr(&M.dirty[ck >> 5], 1u << (ck & 31));
         }
     }
+    __syncthreads();
+    bool leftover = false;
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < FW; ++i) {
+            const uint32_t l = M.dirty[i];
+            if (l) { leftover = true; atomicOr(&gs[TM_GS_GC_FLAGS + i], (int)l); }
+        }
+        atomicAdd(&gs[TM_GS_GC_MARK_CYC], (int)(((long long)__builtin_readcyclecounter() - t_begin) >> 6));
+    }
+    if (lane == 0) {
+        atomicAdd(&gs[TM_GS_GC_BLOCKS], n_blocks); atomicAdd(&gs[TM_GS_GC_ITERS], n_iters); atomicAdd(&gs[TM_GS_GC_IDLE_TURNS], n_idle);
+        atomicAdd(&gs[TM_GS_GC_CYC_LOAD], (int)(cyc_load >> 6)); atomicAdd(&gs[TM_GS_GC_CYC_ROUNDS], (int)(cyc_rounds >> 6));
+        atomicAdd(&gs[TM_GS_GC_CYC_WAVES], (int)(((long long)__builtin_readcyclecounter() - t_begin) >> 6));
+    }
+    if (LDSM) {
+        for (int i = w_lo + tid; i < w_hi; i += T) {
+            // A node that is still pending (the deadline came before its block) goes back PENDING, NOT MARKED: the next
+            // launch's owner drops what it is sent and finds marked ("looked at, or pending with me" - its own LDS is gone by then).
+            const uint32_t q = pd[i], l = nm[i] & ~q;
+            // (bit 0 of word 0 is node 0's: set above by whoever saw a zero; the game's write barrier is setting bits too)
+            if (!spec && i != 0) gnm[i] = l;
+            else if (l & ~gnm[i]) atomicOr(gnm + i, l);
+            if (q) atomicOr(gpd + i, q);                     // (nodes of the blocks that are still flagged)
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (what this workgroup sent and flagged is in memory before it arrives)
     __syncthreads();                   // (the LDS bitmaps may be the next game's now)
-    return leftover;
+    return leftover;                   // (thread 0's)
 }
 
 __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags, int n_gc, GcLds& M) {
@@ -2207,13 +2398,14 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
     // THE LAUNCH'S PLAN (every workgroup derives the same one: the control words it reads were written in earlier launches,
     // or are written in this one only after every workgroup has arrived for the game).
     // The bounded steps first, as many as fit the launch's cost allowance - those of the waiting games oldest request first,
-    // then the speculative markings' starting at a game that rotates with the launch number; then the markings: ONE marking
-    // workgroup per game (gc_sweep_mark: the bitmaps of the game it marks live in its LDS), the games dealt round the marking
-    // workgroups in the same order, a workgroup's time shared between its games when there are more games than workgroups.
+    // then the speculative markings' starting at a game that rotates with the launch number; then the markings: the marking
+    // workgroups are dealt to the marked games in the same order - up to GC_MARK_WGS_MAX a game, each the owner of a share of
+    // the game's index range (gc_sweep_mark: the bitmaps of its share live in its LDS); more games than workgroups: one
+    // workgroup a game, its time shared between its games.
     // Workgroups [0, n_b) do the bounded steps, [n_b, n_gc) the marking (a lone workgroup does both): a launch's bounded work
-    // must not take the marking's time, nor the other way round.  A collection's FIRST step is both: the tables are cleared by
-    // the bounded workgroups while the game's marking workgroup begins the marking (init of a blocking request), or takes it
-    // to its end (GC_REQ_SPEC: the game has stopped, what its barrier flagged is all there).
+    // must not take the marking's time, nor the other way round.  The step that follows a speculative marking (GC_REQ_SPEC:
+    // the game has stopped, what its barrier sent is all there) is both: the tables are cleared by the bounded workgroups while
+    // the game's marking workgroups take the marking to its end.
     // EVERY workgroup arrives for every game whose step is performed, with or without a share of the work: nobody moves a
     // game on before everybody has read its control words.  Arrivals without a share are made first, one thread per game,
     // all in flight together (a speculative marking with nothing flagged - GC_IDLE - is nothing but that: the last arriver
@@ -2262,13 +2454,22 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                     my_part = c < n_b ? c : -1;
                 }
                 M.list_part[k] = my_part; M.list_parts[k] = n_parts;
-                if (step == GCP_MARK || step == GCP_INIT || step == GC_REQ_SPEC) M.mk_list[n_mk++] = (short)k;
+                if (step == GCP_MARK || step == GC_REQ_SPEC) M.mk_list[n_mk++] = (short)k;
             }
         }
-        // the marked games round the marking workgroups; `share` = the games this workgroup still has before it, this one included
-        for (int j = 0; j < n_mk; ++j) {
-            const int k = M.mk_list[j];
-            if (cm >= 0 && j % n_m == cm) { M.list_mark[k] = 1; M.list_share[k] = (short)((n_mk - 1 - j) / n_m + 1); }
+        // the marking workgroups round the marked games
+        {
+            const int per = n_mk == 0 ? 0 : min(GC_MARK_WGS_MAX, n_m / n_mk);
+            for (int j = 0; j < n_mk; ++j) {
+                const int k = M.mk_list[j];
+                if (per >= 1) {          // every game its own workgroups: [j * per, (j + 1) * per)
+                    if (cm >= j * per && cm < (j + 1) * per) {
+                        M.list_mark[k] = 1; M.list_mpart[k] = (unsigned char)(cm - j * per); M.list_mparts[k] = (unsigned char)per; M.list_share[k] = 1;
+                    }
+                } else if (cm >= 0 && j % n_m == cm) {      // `share` = the games this workgroup still has before it, this one included
+                    M.list_mark[k] = 1; M.list_mpart[k] = 0; M.list_mparts[k] = 1; M.list_share[k] = (short)((n_mk - 1 - j) / n_m + 1);
+                }
+            }
         }
         // this workgroup's work, in order: bounded shares (waiting games by age, then the others), then its markings
         for (int cls = 0; cls < 2; ++cls) {
@@ -2286,31 +2487,42 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
     }
     __syncthreads();
     // a single thread, after its workgroup's stores for the game: arrive; the last workgroup to arrive moves the game on
+    // (two uniform values the steps' ends store: taken from their scalar registers where they are stored - kept in vector
+    // registers across the marking loop they were the kernel's only spills)
+    auto vreg = [](int x) { int v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x)); return v; };
     auto arrive = [&](int k, bool leftover) {
         const int g = M.list_g[k], word_seen = M.list_ph[k], step = M.list_step[k];
         const bool spec = (word_seen & 15) == GC_SPEC_MARK;       // the game is simulating
         int32_t* gs = S.gs + (size_t)g * TM_GS_DW;
         bool any_left = false;
         if (!gc_arrive(gs, n_gc, leftover, any_left, !spec && step != GC_SPEC_REQ)) return;
+        // what is left of a marking: what a marking workgroup said when it arrived, and the flags that are up now (raised for
+        // a share whose owner had left already, or by the game's barrier; every marking workgroup's flags were in memory before
+        // it arrived)
+        auto flags_up = [&]() {
+            int f = 0;
+            for (int i = 0; i < TM_GC_FLAG_WORDS; ++i) f |= atomicOr(&gs[TM_GS_GC_FLAGS + i], 0);
+            return f != 0;
+        };
         if (step == GCP_INIT) {
-            gs[TM_GS_GC_NGC] = n_gc;               // the collection is the work of launches with this many collector workgroups
-            gs[TM_GS_GC_PHASE] = any_left ? GCP_MARK : GCP_COUNT;
+            gs[TM_GS_GC_NGC] = vreg(n_gc);         // the collection is the work of launches with this many collector workgroups
+            gs[TM_GS_GC_WORK] = 1;
+            gs[TM_GS_GC_PHASE] = GCP_MARK;
         } else if (step == GC_SPEC_REQ) {
-            gs[TM_GS_GC_NGC] = n_gc;
+            gs[TM_GS_GC_NGC] = vreg(n_gc);
             gs[TM_GS_GC_WORK] = 1;
             // (the game's wave may have turned its request into a blocking one in this very launch - then that stands, and the
             // next launch initialises from scratch)
             atomicCAS(&gs[TM_GS_GC_PHASE], word_seen, GC_SPEC_MARK);
         } else if (step == GC_REQ_SPEC) {
-            // the game has stopped: nothing is flagged any more, and its marker has just taken in what its last launches flagged
-            gs[TM_GS_GC_PHASE] = any_left ? GCP_MARK : GCP_COUNT;
+            // the game has stopped: nothing is sent by its barrier any more, and its markers have just looked at what was
+            gs[TM_GS_GC_PHASE] = (any_left || flags_up()) ? GCP_MARK : GCP_COUNT;
         } else if (step == GCP_MARK || step == GC_IDLE) {
             // a speculative marking never ends by itself (the game may flag chunks after this point), and it does not touch the
             // phase word (the game's wave may have put its blocking request there in this launch)
-            // (what the marker left comes with its arrival; what the barrier has flagged meanwhile is read here - a flag raised after
-            // this is seen by the next launch's last arriver)
-            if (spec) gs[TM_GS_GC_WORK] = (any_left || (atomicOr(&gs[TM_GS_GC_DIRTY0], 0) | atomicOr(&gs[TM_GS_GC_DIRTY1], 0)) != 0) ? 1 : 0;
-            else if (!any_left) gs[TM_GS_GC_PHASE] = GCP_COUNT;
+            const bool left = any_left || flags_up();
+            if (spec) gs[TM_GS_GC_WORK] = left ? 1 : 0;
+            else if (!left) gs[TM_GS_GC_PHASE] = GCP_COUNT;
         } else if (step == GCP_COUNT) {
             gs[TM_GS_GC_PHASE] = GCP_WRITE;
         } else if (step == GCP_WRITE) {
@@ -2332,14 +2544,15 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         } else {      // GCP_OBS
             gs[TM_GS_N_GC] += 1;
             gs[TM_GS_GC_IN_MOVE] = 1;
-            gs[TM_GS_GC_PHASE] = (seq << 4) | GC_DONE;
+            gs[TM_GS_GC_PHASE] = vreg((seq << 4) | GC_DONE);
         }
     };
     if (tid < n_list && M.list_parts[tid] != 0 && M.list_part[tid] < 0 && !M.list_mark[tid]) arrive(tid, false);
     const bool marks_in_lds = gc_marks_in_lds(N);
     for (int e = 0; e < M.n_order; ++e) {
-        const int k = M.order[e];
-        const int g = M.list_g[k], ph = M.list_step[k], my_part = M.list_part[k], n_parts = M.list_parts[k];
+        const int k = __builtin_amdgcn_readfirstlane((int)M.order[e]);
+        const int g = __builtin_amdgcn_readfirstlane(M.list_g[k]), ph = __builtin_amdgcn_readfirstlane(M.list_step[k]);
+        const int my_part = __builtin_amdgcn_readfirstlane((int)M.list_part[k]), n_parts = __builtin_amdgcn_readfirstlane((int)M.list_parts[k]);
         const long long p0 = my_part < 0 ? 0 : my_part, p1 = my_part < 0 ? 0 : my_part + 1;      // share = [x * p0 / n_parts, x * p1 / n_parts)
         const GP P = game_ptrs(S, g);
         int32_t* gs = P.gs();
@@ -2355,16 +2568,21 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                 const long long n4 = S.table_cap / 2;
                 const int lo = (int)(n4 * p0 / n_parts), hi = (int)(n4 * p1 / n_parts);
                 for (int i = lo + tid; i < hi; i += T) { nt4[i] = z4; ot4[i] = z4; }
-            } else if (my_part == g % n_parts) {
-                // a speculative marking begins with the next launch, when the game's write barrier is up: empty bitmaps, the
-                // root marked and its chunk flagged (a blocking request's marker starts from scratch in its own LDS, now)
+            }
+            if (ph != GC_REQ_SPEC && my_part == g % n_parts) {
+                // a marking begins with the next launch (a speculative one: when the game's write barrier is up): empty bitmaps,
+                // the root pending, its chunk flagged
+                uint32_t* pdw = reinterpret_cast<uint32_t*>(S.gc_queue + (size_t)g * N);
                 for (size_t i = tid; i < 2 * bm_bytes / 4; i += T) nmw[i] = 0;      // both bitmaps
+                for (size_t i = tid; i < 2 * bm_bytes / 4; i += T) pdw[i] = 0;      // the pending bits, and what the barrier has sent
                 __syncthreads();
                 if (tid == 0) {
-                    const int root = gs[TM_GS_ROOT], ck = root / gc_chunk_nodes(N);
-                    nmw[root >> 5] = 1u << (root & 31);
-                    atomicExch(&gs[TM_GS_GC_DIRTY0], (root != 0 && ck < 32) ? (int)(1u << ck) : 0);
-                    atomicExch(&gs[TM_GS_GC_DIRTY1], (root != 0 && ck >= 32) ? (int)(1u << (ck - 32)) : 0);
+                    // the root is SENT to the owner of its share (a mark is an owner's to set); the empty tree's root is node 0
+                    const int root = gs[TM_GS_ROOT], ck = root >> gc_chunk_log2(N);
+                    if (root != 0) pdw[root >> 5] = 1u << (root & 31);
+                    else { nmw[0] = 1u; nmw[bm_bytes / 4] = 1u; }
+                    for (int i = 0; i < TM_GC_FLAG_WORDS; ++i)
+                        atomicExch(&gs[TM_GS_GC_FLAGS + i], (root != 0 && (ck >> 5) == i) ? (int)(1u << (ck & 31)) : 0);
                 }
             }
         } else if (ph == GCP_COUNT) {
@@ -2534,22 +2752,31 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
     }
     // the markings of this workgroup (a loop of its own: what a bounded share keeps in registers is dead here)
     for (int e = 0; e < M.n_order; ++e) {
-        const int k = M.order[e];
+        // (what comes out of LDS is the same for every lane - say so: the game's base pointers live in scalar registers)
+        const int k = __builtin_amdgcn_readfirstlane((int)M.order[e]);
         if (!M.list_mark[k]) continue;
-        const GP P = game_ptrs(S, M.list_g[k]);
+        const GP P = game_ptrs(S, __builtin_amdgcn_readfirstlane(M.list_g[k]));
         long long my_deadline = deadline;
         if (M.list_share[k] > 1 && deadline >= 0) {
             const long long t0_ = (long long)__builtin_readcyclecounter();     // thread 0's clock for everybody
             const long long t = ((long long)G_::bcast((int)(t0_ >> 32), tid, sm) << 32) | (unsigned)G_::bcast((int)t0_, tid, sm);
             my_deadline = t >= deadline ? deadline : t + (deadline - t) / M.list_share[k];
         }
-        const bool fresh = M.list_step[k] == GCP_INIT, spec = (M.list_ph[k] & 15) == GC_SPEC_MARK;
-        const bool leftover = marks_in_lds ? gc_sweep_mark<true>(S, P, M, M.marks, fresh, spec, my_deadline, tid, sm)
-                                           : gc_sweep_mark<false>(S, P, M, nullptr, fresh, spec, my_deadline, tid, sm);
+        const bool spec = (__builtin_amdgcn_readfirstlane(M.list_ph[k]) & 15) == GC_SPEC_MARK;
+        const int mp = __builtin_amdgcn_readfirstlane((int)M.list_mpart[k]), mps = __builtin_amdgcn_readfirstlane((int)M.list_mparts[k]);
+        if (tid == 0 && mp == 0) { P.gs()[TM_GS_GC_MARK_PARTS] += mps; P.gs()[TM_GS_GC_MARK_SHARED] += M.list_share[k]; }
         __syncthreads();
-        if (tid == 0) arrive(k, leftover);
-        __syncthreads();
+        const bool leftover = marks_in_lds ? gc_sweep_mark<true>(S, P, M, M.marks, mp, mps, spec, my_deadline, tid, sm)
+                                           : gc_sweep_mark<false>(S, P, M, nullptr, mp, mps, spec, my_deadline, tid, sm);
+        if (tid == 0) M.list_share[k] = (short)(leftover ? -2 : -1);      // (what this workgroup says when it arrives: below)
     }
+    // ... and its arrivals for them (a loop of its own: the values the ends of the steps store are not the marker's to carry)
+    __syncthreads();
+    if (tid == 0)
+        for (int e = 0; e < M.n_order; ++e) {
+            const int k = M.order[e];
+            if (M.list_mark[k]) arrive(k, M.list_share[k] == -2);
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2577,6 +2804,8 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_sim_step(tm_store S, int flags)
         // drew from before this launch) is cleared for the next one
         if (blockIdx.x == 0 && (flags & TM_SIM_FRONT) && (int)threadIdx.x < TM_EVAL_SEGS(S.n_games))
             S.eval_cnt[(size_t)threadIdx.x * 2 + (S.eval_parity ^ 1)] = 0;
+        // (a collector wave shares its SIMD with four simulation waves and is the one a blocked game waits for: it goes first)
+        __builtin_amdgcn_s_setprio(3);
         gc_collector_block(S, flags, n_gc, *reinterpret_cast<GcLds*>(sim_lds));
         return;
     }
