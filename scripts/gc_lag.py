@@ -12,9 +12,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--games", type=int, default=4096); ap.add_argument("--max-nodes", type=int, default=100000)
 ap.add_argument("--sims", type=int, default=500); ap.add_argument("--moves", type=int, default=6)
 ap.add_argument("--warm-moves", type=int, default=75); ap.add_argument("--gc-spec-nodes", type=int, default=None)
+ap.add_argument("--checkpoint", default=None, help="value-net checkpoint (the trained regime)")
+ap.add_argument("--native-moves", type=int, default=0, help="after the traced moves: this many moves through the native loop, counters only")
 a = ap.parse_args()
 env_args = ((20, 10), 1, 0, 0)
 model = Model_VV(backend="hip", seed=0)
+if a.checkpoint: model.load(a.checkpoint, verbose=False)
 game = Tetris(*env_args, seed=20260925 + np.arange(a.games, dtype=np.int64), n_games=a.games)
 agent = agents.ValueSim(sims=a.sims, env=Tetris, env_args=env_args, n_games=a.games, max_nodes=a.max_nodes, model=model,
                         online=False, gc_spec_nodes=a.gc_spec_nodes)
@@ -48,6 +51,16 @@ for m in range(a.moves):
         print("   game %4d lag %3d collections %d stalled launches %3d speculative launches %3d free nodes %5d reachable at last gc %5d phase %2d pool_full %d slices %d"
               % (g, lag[g], ngc[g], stall[g], spec[g], g1[g, 2], g1[g, 24], g1[g, 32] & 15, g1[g, 44], g1[g, 38] - g0[g, 38]))
         print("        launches by phase [req, mark, count, write, nodes, obs, done | spec-req, spec-mark, req-spec, -, req-over]:", hist[g, 1:8].tolist(), hist[g, 8:13].tolist())
+    col = ngc >= 1
+    if col.any():
+        names = ["req", "mark", "count", "write", "nodes", "obs", "done", "spec-req", "spec-mark", "req-spec", "-", "req-over"]
+        print("   games that collected (%d): launches by phase, mean per collection: %s" % (int(col.sum()),
+              ", ".join("%s %.1f" % (n, hist[col, 1 + i].sum() / ngc[col].sum()) for i, n in enumerate(names))))
+        first = np.array([np.argmax(hist[g, 1:8] > 0) if hist[g, 1:8].any() else -1 for g in np.nonzero(col)[0]])
+        print("   marker per collection in this move: launches %.1f, blocks %.0f, workgroups per launch %.2f, games per workgroup %.2f" % (
+              (g1[col, 37] - g0[col, 37]).sum() / ngc[col].sum(), (g1[col, 51] - g0[col, 51]).sum() / ngc[col].sum(),
+              (g1[col, 58] - g0[col, 58]).sum() / max(1, (g1[col, 37] - g0[col, 37]).sum()),
+              (g1[col, 59] - g0[col, 59]).sum() / max(1, (g1[col, 37] - g0[col, 37]).sum())))
     one = ngc == 1
     if one.any():
         print("   games with one collection: stalled launches mean %.1f max %d; speculative launches mean %.1f" % (stall[one].mean(), stall[one].max(), spec[one].mean()))
@@ -61,4 +74,15 @@ for m in range(a.moves):
             agent.evaluate_requests(); s.sim_step(both); n_catch += 1
         todo, collecting = s.sims_remaining()
     print("   catch-up launches", n_catch, flush=True)
+    finish_move()
+
+for m in range(a.native_moves):
+    g0 = s.t["gs"].cpu().numpy().copy()
+    s.search_stats(1, 0, reset=True)
+    s.search(a.sims, model)
+    ss = s.search_stats(1, 0, reset=False)
+    g1 = s.t["gs"].cpu().numpy()
+    ngc = (g1[:, 9] - g0[:, 9]).sum()
+    print("native move %d: collections %d, waiting launches per collection %.1f, marker launches per collection %.1f, catch-up launches %d, collector-only launches %d"
+          % (m, ngc, (g1[:, 38] - g0[:, 38]).sum() / max(1, ngc), (g1[:, 37] - g0[:, 37]).sum() / max(1, ngc), ss["catchup_launches"], ss["gc_launches"]), flush=True)
     finish_move()

@@ -2435,55 +2435,88 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         M.by_age[rank] = (short)tid;
     }
     __syncthreads();
-    if (tid == 0) {
-        int cost_left = deadline < 0 ? 1 << 20 : (S.gc_cost_units > 0 ? S.gc_cost_units : GC_COST_MAX), n_order = 0, n_mk = 0;      // (collector-only launches: nothing to hold up)
-        const int cm = n_gc >= 2 ? c - n_b : 0;           // index among the marking workgroups (< 0: not one of them)
-        for (int cls = 0; cls < 2; ++cls) {               // the waiting games, then the speculative markings
-            const int first = cls ? n_wait : 0, n = cls ? n_spec : n_wait;
-            for (int i = 0; i < n; ++i) {
-                const int k = cls == 0 ? M.by_age[i] : first + (i + seq) % n;
-                const int step = M.list_step[k];
-                int my_part = -1, n_parts = 1;
-                M.list_share[k] = 0;
-                if (step == GC_FOREIGN) { M.list_parts[k] = 0; continue; }      // nobody arrives
-                if (step != GC_IDLE && step != GCP_MARK) {                      // (GC_IDLE: everybody just arrives)
-                    const int cost = step == GCP_WRITE ? 2 : (step == GCP_NODES || step == GCP_OBS) ? 5 : 1;      // init / clear / count: 1
-                    if (cost > cost_left) { M.list_parts[k] = 0; continue; }      // not in this launch: nobody arrives
-                    cost_left -= cost;
-                    n_parts = n_b;
-                    my_part = c < n_b ? c : -1;
+    // The plan, one list entry a thread (position p of the plan's order = the waiting games by age, then the speculative markings
+    // from a game that rotates with the launch number), a few prefix sums over the workgroup, and ONE short loop of one thread:
+    // the greedy choice of the bounded steps, over the entries that have one.  (Until r06 the whole plan was one thread's loop
+    // over the list - 128 000 cycles of dependent LDS accesses with a full list, the launch's whole allowance: with two hundred
+    // games waiting no marker had time left, and the trained net's steady state stayed there.)
+    const int cm = n_gc >= 2 ? c - n_b : 0;           // index among the marking workgroups (< 0: not one of them)
+    {
+        const int p = tid;
+        const bool in_plan = p < n_list;
+        const int k = !in_plan ? 0 : p < n_wait ? (int)M.by_age[p] : n_wait + ((p - n_wait) + seq) % n_spec;
+        const int step = in_plan ? M.list_step[k] : GC_FOREIGN;
+        const bool bounded = in_plan && step != GC_FOREIGN && step != GC_IDLE && step != GCP_MARK;
+        const int cost = !bounded ? 0 : step == GCP_WRITE ? 2 : (step == GCP_NODES || step == GCP_OBS) ? 5 : 1;      // init / clear / count: 1
+        // 1. the entries with a bounded step, in the plan's order, and one thread's greedy pass over them
+        int n_bd;
+        const int bpos = G_::exscan(bounded ? 1 : 0, tid, sm, n_bd);
+        if (bounded) { M.order[bpos] = (short)k; M.mk_list[bpos] = (short)cost; }        // (both lists are rebuilt below)
+        if (in_plan) M.list_parts[k] = bounded ? 0 : 1;      // (a bounded step: until the greedy pass has taken it)
+        __syncthreads();
+        if (tid == 0) {
+            int cost_left = deadline < 0 ? 1 << 20 : (S.gc_cost_units > 0 ? S.gc_cost_units : GC_COST_MAX);      // (collector-only launches: nothing to hold up)
+            for (int i = 0; i < n_bd && cost_left > 0; ++i) {
+                const int ci = M.mk_list[i];
+                if (ci <= cost_left) { cost_left -= ci; M.list_parts[M.order[i]] = (short)n_b; }      // performed (its shares: the bounded workgroups)
+            }
+        }
+        __syncthreads();
+        // 2. what is performed in this launch, and this workgroup's share of it
+        const bool performed = in_plan && step != GC_FOREIGN && (!bounded || M.list_parts[k] != 0);
+        __syncthreads();
+        if (in_plan) {
+            M.list_parts[k] = (short)(!performed ? 0 : bounded ? n_b : 1);      // 0: not in this launch, nobody arrives
+            M.list_part[k] = (short)((performed && bounded && c < n_b) ? c : -1);
+            M.list_share[k] = 0;
+        }
+        // 3. the marked games in the plan's order (the waiting ones first), and the marking workgroups round them
+        const bool marked = performed && (step == GCP_MARK || step == GC_REQ_SPEC);
+        int n_mk, n_mw;
+        const int j = G_::exscan(marked ? 1 : 0, tid, sm, n_mk);
+        G_::exscan((marked && p < n_wait) ? 1 : 0, tid, sm, n_mw);
+        // A game that WAITS for its marking gets whole workgroups, up to GC_MARK_WGS_MAX, each the owner of a share of its index
+        // range; the speculative markings get what is left the same way, or - more of them than workgroups - take turns on them:
+        // a workgroup does its games one after the other, each until its work list is empty or the launch's deadline (most of them
+        // have a few blocks to look at: what the game's barrier has sent since the last launch); the one it does not get to stays
+        // as it is.  (r06, measured: with the workgroups dealt evenly and the time of a shared workgroup divided, every marking
+        // ran on a fraction of a slice minus its fixed costs.)
+        const int n_ms = n_mk - n_mw;
+        // (a quarter of the workgroups stays with the speculative markings while there are any: a marking that is done when its
+        // game's pool runs dry costs the game one launch, not the marking's)
+        const int keep = min(n_ms, n_m / 4);
+        const int per_w = n_mw == 0 ? 0 : min(GC_MARK_WGS_MAX, (n_m - keep) / n_mw);      // 0: more waiting games than workgroups
+        const int used_w = n_mw == 0 ? 0 : per_w >= 1 ? n_mw * per_w : n_m - keep;
+        const int rem = n_m - used_w;
+        const int per_s = n_ms == 0 ? 0 : min(GC_MARK_WGS_MAX, rem / n_ms);              // 0: the speculative markings take turns (or wait)
+        bool mine = false;
+        if (marked) {
+            const bool waiting = j < n_mw;
+            const int jj = waiting ? j : j - n_mw, per = waiting ? per_w : per_s, first = waiting ? 0 : used_w, pool = waiting ? used_w : rem;
+            if (per >= 1) {          // its own workgroups: [first + jj * per, first + (jj + 1) * per)
+                if (cm >= first + jj * per && cm < first + (jj + 1) * per) {
+                    mine = true; M.list_mpart[k] = (unsigned char)(cm - first - jj * per); M.list_mparts[k] = (unsigned char)per;
                 }
-                M.list_part[k] = my_part; M.list_parts[k] = n_parts;
-                if (step == GCP_MARK || step == GC_REQ_SPEC) M.mk_list[n_mk++] = (short)k;
+                M.list_share[k] = 1;
+            } else if (pool >= 1) {  // a workgroup of the pool, with others
+                if (cm >= 0 && first + jj % pool == cm) { mine = true; M.list_mpart[k] = 0; M.list_mparts[k] = 1; }
+                M.list_share[k] = (short)((waiting ? n_mw : n_ms) / pool + 1);
+            } else if (step == GCP_MARK) {
+                M.list_parts[k] = 0;             // no workgroup left for it in this launch: nobody arrives
             }
+            // (GC_REQ_SPEC without a marking workgroup: the tables are cleared, the marking goes on in the next launch - its flags
+            // are up)
+            if (mine) M.list_mark[k] = 1;
         }
-        // the marking workgroups round the marked games
-        {
-            const int per = n_mk == 0 ? 0 : min(GC_MARK_WGS_MAX, n_m / n_mk);
-            for (int j = 0; j < n_mk; ++j) {
-                const int k = M.mk_list[j];
-                if (per >= 1) {          // every game its own workgroups: [j * per, (j + 1) * per)
-                    if (cm >= j * per && cm < (j + 1) * per) {
-                        M.list_mark[k] = 1; M.list_mpart[k] = (unsigned char)(cm - j * per); M.list_mparts[k] = (unsigned char)per; M.list_share[k] = 1;
-                    }
-                } else if (cm >= 0 && j % n_m == cm) {      // `share` = the games this workgroup still has before it, this one included
-                    M.list_mark[k] = 1; M.list_mpart[k] = 0; M.list_mparts[k] = 1; M.list_share[k] = (short)((n_mk - 1 - j) / n_m + 1);
-                }
-            }
-        }
-        // this workgroup's work, in order: bounded shares (waiting games by age, then the others), then its markings
-        for (int cls = 0; cls < 2; ++cls) {
-            const int first = cls ? n_wait : 0, n = cls ? n_spec : n_wait;
-            for (int i = 0; i < n; ++i) {
-                const int k = cls == 0 ? M.by_age[i] : first + (i + seq) % n;
-                if (M.list_parts[k] != 0 && M.list_part[k] >= 0) M.order[n_order++] = (short)k;
-            }
-        }
-        for (int j = 0; j < n_mk; ++j) {
-            const int k = M.mk_list[j];
-            if (M.list_mark[k] && M.list_part[k] < 0) M.order[n_order++] = (short)k;
-        }
-        M.n_order = n_order;
+        __syncthreads();             // (the two lists of step 1 have been read)
+        // 4. this workgroup's work, in the plan's order: its bounded shares, then its markings
+        int n_sh, n_mine;
+        const bool share = in_plan && M.list_parts[k] != 0 && M.list_part[k] >= 0;
+        const int spos = G_::exscan(share ? 1 : 0, tid, sm, n_sh);
+        const int mpos = G_::exscan((mine && !share) ? 1 : 0, tid, sm, n_mine);
+        if (share) M.order[spos] = (short)k;
+        if (mine && !share) M.order[n_sh + mpos] = (short)k;
+        if (tid == 0) M.n_order = n_sh + n_mine;
     }
     __syncthreads();
     // a single thread, after its workgroup's stores for the game: arrive; the last workgroup to arrive moves the game on
@@ -2756,11 +2789,11 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         const int k = __builtin_amdgcn_readfirstlane((int)M.order[e]);
         if (!M.list_mark[k]) continue;
         const GP P = game_ptrs(S, __builtin_amdgcn_readfirstlane(M.list_g[k]));
-        long long my_deadline = deadline;
-        if (M.list_share[k] > 1 && deadline >= 0) {
-            const long long t0_ = (long long)__builtin_readcyclecounter();     // thread 0's clock for everybody
-            const long long t = ((long long)G_::bcast((int)(t0_ >> 32), tid, sm) << 32) | (unsigned)G_::bcast((int)t0_, tid, sm);
-            my_deadline = t >= deadline ? deadline : t + (deadline - t) / M.list_share[k];
+        const long long my_deadline = deadline;      // (a shared workgroup: one game after the other, see the plan)
+        // the deadline has come before this game's turn: it stays as it is (and its marking workgroup says so when it arrives)
+        if (G_::bcast((deadline >= 0 && (long long)__builtin_readcyclecounter() > deadline) ? 1 : 0, tid, sm)) {
+            if (tid == 0) M.list_share[k] = (short)-2;
+            continue;
         }
         const bool spec = (__builtin_amdgcn_readfirstlane(M.list_ph[k]) & 15) == GC_SPEC_MARK;
         const int mp = __builtin_amdgcn_readfirstlane((int)M.list_mpart[k]), mps = __builtin_amdgcn_readfirstlane((int)M.list_mparts[k]);
