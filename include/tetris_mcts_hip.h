@@ -351,6 +351,14 @@ int tm_distpy_backup(int n_trees, int n_nodes, int bins, const int32_t *trace, c
  * change); prepared: TM_VALUENET_PREPARED floats.  tm_valuenet_forward is the matrix-core path (scratch:
  * n x TM_VALUENET_SCRATCH_MFMA floats); tm_valuenet_forward_plain is the one-thread-per-output form with the
  * same fma-chain numerics (scratch: n x TM_VALUENET_SCRATCH floats).  Both are bit-identical by construction. */
+/* The optimiser step of the online fit, model/yogi.py:39-90 (Yogi: lr, betas, eps, coupled weight decay) over FLAT device buffers:
+ * p (parameters), g (gradients), m / v (exp_avg / exp_avg_sq), n floats each; state = 8 doubles on the device, zero before the first
+ * step ([0] the step count, [1] [2] beta^t, [3] lr / (1 - beta1^t), [4] sqrt(1 - beta2^t): advanced on the device, so that the call is
+ * the same two launches every time and can be captured in a HIP graph).  Per element the reference's operations in its order, fp32,
+ * no contraction; step 1 sets exp_avg = 0, exp_avg_sq = g * g first (yogi.py:62-66).  Replaces the per-tensor loop of
+ * Yogi.step (12 parameters x 8 launches). */
+int tm_yogi_step(float *p, const float *g, float *m, float *v, double *state, int n, double lr, double beta1, double beta2,
+                 double eps, double weight_decay, void *stream);
 int tm_valuenet_prepare(const float *params, float *prepared, void *stream);
 int tm_valuenet_forward(const float *params, const float *prepared, const int8_t *states, int n, float *v, float *var,
                         float *scratch, void *stream);

@@ -12,5 +12,5 @@ sed -i 's#"../../include/tetris_mcts_hip.h"#"'$PWD'/include/tetris_mcts_hip.h"#'
 cp tetris_mcts_amd/csrc/*.h tetris_mcts_amd/csrc/*.inc /tmp/tmv_$NAME/ 2>/dev/null || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c /tmp/tmv_$NAME/tree.hip -o /tmp/tmv_$NAME/tree.o
 O=tetris_mcts_amd/csrc/_obj
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/tmv_$NAME/tree.o $O/search.o $O/core_api.o $O/valuenet.o $O/distnet.o -o build_variants/$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/tmv_$NAME/tree.o $O/search.o $O/core_api.o $O/valuenet.o $O/distnet.o $O/yogi.o -o build_variants/$NAME.so
 echo "build_variants/$NAME.so"

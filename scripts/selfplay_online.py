@@ -51,6 +51,7 @@ agent = getattr(agents, args.agent)(sims=args.sims, env=Tetris, env_args=env_arg
                                     model=model, online=not args.no_train, replay_cap=0 if args.no_train else 16384, **extra)
 agent.update_root(game)
 t0 = t_round = time.time()
+train_total = 0.0
 moves, rounds = 0, 0
 ep_lines, ep_scores, ep_len = [], [], []
 alive = np.zeros(G, np.int64)
@@ -81,6 +82,7 @@ while time.time() - t0 < args.minutes * 60:
         tt = time.time()
         res = None if args.no_train else agent.train_nodes(iters_per_val=100, batch_size=1024, max_iters=args.train_iters, log=False)
         rounds += 1
+        train_total += time.time() - tt
         rec = dict(round=rounds, t=round(time.time() - t0, 1), moves=moves, episodes=len(ep_lines),
                    mean_lines=float(np.mean(ep_lines)) if ep_lines else None,
                    max_lines=int(np.max(ep_lines)) if ep_lines else None,
@@ -89,7 +91,9 @@ while time.time() - t0 < args.minutes * 60:
                    lines_per_1000_moves=1000.0 * lines_round / max(moves_round, 1),
                    mean_lines_all_episodes_under_way=float(np.mean(list(ep_lines) + list(prev_lines))),
                    new_tuples=tuples, trained=res is not None, train_iters=(res or {}).get("iters"),
-                   best_val=(res or {}).get("best_validation"), train_s=round(time.time() - tt, 1),
+                   best_val=(res or {}).get("best_validation"), train_s=round(time.time() - tt, 2),
+                   train_ms_per_iter=(1e3 * (time.time() - tt) / res["iters"]) if res and res.get("iters") else None,
+                   train_share_of_wall_so_far=round(train_total / max(time.time() - t0, 1e-9), 3),
                    gcs=agent.store.counter("N_GC"), gc_slices=agent.store.counter("GC_SLICES"),
                    dropped_tuples=agent.store.counter("N_DROPPED"), pool_resets=agent.store.counter("N_POOL_RESET"),
                    **{k: int((agent.store.search_stats(agent.n_sub, agent.ev_every, reset=False) or {}).get(k, 0))

@@ -38,6 +38,9 @@ def _worker(rank, world, port, q):
     episodes = tdist.all_sum(3 + rank)
     mem = ReplayMemory(accumulation_policy=2, memory_size=6, episodes_per_train=50)
     out = mem.absorb(ka, sa, episodes)
+    # the job's replay memory (ValueSim.train_nodes): 9 of the ranks' 5 + 2 tuples would fit - 6 is the memory's size
+    kj, sj = tdist.job_memory(6, ka, sa)
+    assert kj.shape[0] == 6 and torch.equal(kj, ka[:6]) and torch.equal(sj, sa[:6])
     q.put((rank, ka.numpy(), sa.numpy(), tdist.shard_range(4099, rank, world), episodes, out[0].numpy(), tdist.rank()))
     dist.barrier()
     dist.destroy_process_group()
@@ -62,6 +65,7 @@ def test_all_gather_tuples_gloo_world2():
         assert np.array_equal(ka, exp_k) and sa.tobytes() == exp_s.tobytes()
         assert episodes == 7 and my_rank == rank
         assert np.array_equal(train_keys, exp_k[:6])       # policy 2: the memory (6 of the 7 tuples) filled up -> train
+        assert len(exp_k) == 7                             # (the ranks' 5 + 2 tuples overflow a memory of 6: job_memory above cut them, rank 0's first)
         shards.append(sh)
     assert shards[0][0] == 0 and shards[0][0] + shards[0][1] == shards[1][0] and shards[1][0] + shards[1][1] == 4099
 

@@ -55,6 +55,7 @@ SYMBOLS = {
     "tm_core_backup_trace_obs_lp": [i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, i32, i32, vp],
     "tm_core_get_unique_child_obs": [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "tm_core_get_all_childs": [i32, i32, vp, vp, vp, vp, vp],
+    "tm_yogi_step": [vp, vp, vp, vp, vp, i32, f64, f64, f64, f64, f64, vp],
     "tm_valuenet_prepare": [vp, vp, vp],
     "tm_valuenet_forward": [vp, vp, vp, i32, vp, vp, vp, vp],
     "tm_valuenet_forward_plain": [vp, vp, i32, vp, vp, vp, vp],

@@ -128,6 +128,7 @@ class DistValueSim(TreeAgent):
             keys, dists, visits = (torch.cat([a, b]) for a, b in zip(self._memory, (keys, dists, visits)))
         keys, dists, visits = keys[:self.memory_size], dists[:self.memory_size], visits[:self.memory_size]
         keys_all, dists_all, visits_all = tdist.all_gather_rows(keys.view(torch.int32), dists, visits)
+        keys_all, dists_all, visits_all = tdist.job_memory(self.memory_size, keys_all, dists_all, visits_all)      # (memory_size is the job's)
         d_size = int(keys_all.shape[0])
         m_size = min(self.n_trains * self.memory_growth_rate, self.memory_size)
         if d_size < max(m_size, 1):

@@ -79,7 +79,10 @@ class ValueSim(TreeAgent):
         self._train_calls = getattr(self, "_train_calls", 0) + 1
         if self._train_calls % max(1, int(every)):
             return None
-        if tdist.all_sum(int(self.store.t["replay_count"].sum().item()), self.store.device) < max(1, int(min_tuples)):
+        # (what an earlier look moved into the host-side memory - "not enough training data" - counts: it is part of the next
+        # fit's set.  Every rank must call this on the same moves: the count is a collective)
+        held = 0 if self._memory is None else int(self._memory[0].shape[0])
+        if tdist.all_sum(int(self.store.t["replay_count"].sum().item()) + held, self.store.device) < max(1, int(min_tuples)):
             return None
         return self.train_nodes(**kwargs)
 
@@ -104,6 +107,7 @@ class ValueSim(TreeAgent):
             stats = torch.cat([self._memory[1], stats])
         keys, stats = keys[:self.memory_size], stats[:self.memory_size]
         keys_all, stats_all = tdist.all_gather_tuples(keys.view(torch.int32), stats)
+        keys_all, stats_all = tdist.job_memory(self.memory_size, keys_all, stats_all)      # (memory_size is the job's, not a rank's)
         d_size = keys_all.shape[0]
         m_size = min(self.n_trains * self.memory_growth_rate, self.memory_size)
         if d_size < max(m_size, 1):

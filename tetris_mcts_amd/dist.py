@@ -94,6 +94,8 @@ def all_gather_rows(*cols, group=None):
     n_loc = cols[0].shape[0]
     # explicit widths: a rank that has not harvested yet has 0 rows (collections are not synchronised over the ranks), and
     # reshape(0, -1) is refused - it must still take part in both collectives, or the others hang
+    if any(c.element_size() != 4 for c in cols):
+        raise TypeError("all_gather_rows: 4-byte elements only (the columns travel bit-cast to int32): " + ", ".join(str(c.dtype) for c in cols))
     widths = [max(1, math.prod(c.shape[1:])) for c in cols]
     flat = [c.reshape(n_loc, w).contiguous().view(torch.int32) for c, w in zip(cols, widths)]
     n = torch.tensor([n_loc], dtype=torch.int64, device=dev)
@@ -114,6 +116,14 @@ def all_gather_rows(*cols, group=None):
         res.append(allp[:, off:off + w].contiguous().view(c.dtype).reshape((allp.shape[0],) + tuple(c.shape[1:])))
         off += w
     return tuple(res)
+
+
+def job_memory(memory_size, *cols):
+    """The all-gathered training tuples cut to the JOB's replay memory: `memory_size` is what the reference's one process holds
+    for all its games (agents/ValueSim.py:14, 122-159: store_nodes stops at memory_size), so P ranks together keep the first
+    memory_size tuples of the gathered set - rank after rank, each rank's tuples in the order of its harvest: the same on every
+    rank - not P times that."""
+    return tuple(c[:memory_size] for c in cols)
 
 
 def render_observations(obs_keys):

@@ -20,12 +20,106 @@ variance_bound = 1e-1
 
 class Yogi(Optimizer):
     """Yogi (Zaheer et al. 2018) with the reference's conventions: v0 = g0^2 (before weight decay), coupled weight
-    decay added to the gradient, bias-corrected step  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)."""
+    decay added to the gradient, bias-corrected step  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
 
-    def __init__(self, params, lr=1e-2, betas=(0.9, 0.999), eps=1e-3, weight_decay=0.0):
+    Parameters on the GPU: the step is ONE HIP kernel over flat buffers (csrc/yogi.hip `tm_yogi_step`: the same operations per
+    element in the same order) - the parameters, their gradients and the two moments become views of four flat tensors at the
+    first step (`flatten`), the step count lives on the device, and an iteration of the fit is a fixed sequence of launches
+    that train_data replays from a HIP graph.  The state dict keeps the reference's layout (per parameter: step, exp_avg,
+    exp_avg_sq), so checkpoints load on either side.  Parameters on the CPU: the reference's own sequence of tensor operations."""
+
+    def __init__(self, params, lr=1e-2, betas=(0.9, 0.999), eps=1e-3, weight_decay=0.0, fused=None):
         if lr <= 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Yogi hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._fused_wanted = fused
+        self._flat = None
+
+    # ---- the fused form ----
+    def fused(self):
+        """whether step() is the one-kernel form: every parameter on one GPU, float32, a single group (or asked for / refused
+        at construction)"""
+        if self._fused_wanted is False:
+            return False
+        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        ok = (len(self.param_groups) == 1 and len(ps) > 0 and all(p.is_cuda and p.dtype == torch.float32 for p in ps)
+              and len({p.device for p in ps}) == 1)
+        if self._fused_wanted and not ok:
+            raise ValueError("Yogi(fused=True) needs float32 parameters on one GPU in a single group")
+        return ok
+
+    def flatten(self):
+        """(idempotent) the parameters that take gradients, their gradients and moments as views of flat buffers"""
+        if self._flat is not None:
+            return self._flat
+        ps = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        dev, n = ps[0].device, sum(p.numel() for p in ps)
+        F = dict(params=ps, n=n, p=torch.empty(n, device=dev), g=torch.zeros(n, device=dev), m=torch.zeros(n, device=dev),
+                 v=torch.zeros(n, device=dev), state=torch.zeros(8, dtype=torch.float64, device=dev))
+        off, steps = 0, set()
+        with torch.no_grad():
+            for p in ps:
+                k = p.numel()
+                sl = slice(off, off + k)
+                F["p"][sl].copy_(p.reshape(-1))
+                p.data = F["p"][sl].view_as(p)
+                if p.grad is not None:
+                    F["g"][sl].copy_(p.grad.reshape(-1))
+                p.grad = F["g"][sl].view_as(p)
+                st = self.state[p]
+                if st:       # moments loaded from a checkpoint (or steps taken by the per-tensor form)
+                    F["m"][sl].copy_(st["exp_avg"].reshape(-1))
+                    F["v"][sl].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(int(st["step"]))
+                st["exp_avg"], st["exp_avg_sq"] = F["m"][sl].view_as(p), F["v"][sl].view_as(p)
+                st.setdefault("step", 0)
+                off += k
+        if len(steps) > 1:
+            raise ValueError("Yogi: the parameters' step counts differ (%s)" % sorted(steps))
+        t = steps.pop() if steps else 0
+        b1, b2 = self.param_groups[0]["betas"]
+        lr = self.param_groups[0]["lr"]
+        if t > 0:
+            F["state"].copy_(torch.tensor([t, b1 ** t, b2 ** t, lr / (1 - b1 ** t), math.sqrt(1 - b2 ** t), 0, 0, 0], dtype=torch.float64))
+        F["t"] = t
+        self._flat = F
+        return F
+
+    def flat_grad(self):
+        return self.flatten()["g"] if self.fused() else None
+
+    def zero_grad(self, set_to_none=True):
+        if self._flat is not None:
+            self._flat["g"].zero_()      # (the gradients stay the views they are: autograd accumulates into them in place)
+            return
+        super().zero_grad(set_to_none=set_to_none)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self._flat is not None:       # the loaded moments are tensors of their own: back into the flat buffers
+            ps = self._flat["params"]
+            with torch.no_grad():
+                for p in ps:
+                    p.data = p.data.clone()
+                    p.grad = None
+            self._flat = None
+            self.flatten()
+
+    def state_dict(self):
+        if self._flat is not None:
+            for p in self._flat["params"]:
+                self.state[p]["step"] = self._flat["t"]
+        return super().state_dict()
+
+    def _fused_step(self):
+        from . import _lib
+        F = self.flatten()
+        g = self.param_groups[0]
+        _lib.check(_lib.lib().tm_yogi_step(F["p"].data_ptr(), F["g"].data_ptr(), F["m"].data_ptr(), F["v"].data_ptr(),
+                                           F["state"].data_ptr(), F["n"], float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                           float(g["eps"]), float(g["weight_decay"]), torch.cuda.current_stream(F["p"].device).cuda_stream),
+                   "tm_yogi_step")
+        F["t"] += 1
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -33,6 +127,9 @@ class Yogi(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self.fused():
+            self._fused_step()
+            return loss
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -78,14 +175,18 @@ def batch_loss(net, batch, weighted, variance_clip=variance_bound):
 
 @torch.no_grad()
 def validation_loss(net, data, weighted, chunk=1024, loss_fn=None):
-    """Weighted combination over chunks (model.py:49-84): chunk weight = sum of sample weights (or the count)."""
-    tot_w, acc, acc2 = 0.0, 0.0, 0.0
+    """Weighted combination over chunks (model.py:49-84): chunk weight = sum of sample weights (or the count).  The chunks'
+    (weight, mean, std) stay on the device until the last one is in: ONE host synchronisation per validation (r05: three per
+    chunk, ~150 per validation of a 50 000-tuple set)."""
     loss_fn = loss_fn or batch_loss
+    rows = []
     for c in range(0, data[0].shape[0], chunk):
         b = [d[c:c + chunk] for d in data]
         mean, std = loss_fn(net, b, weighted)
-        w = float(b[-1].sum()) if weighted else float(b[0].shape[0])
-        mean, std = float(mean), float(std)
+        w = b[-1].sum() if weighted else torch.full((), float(b[0].shape[0]), device=mean.device)
+        rows.append(torch.stack([w.to(torch.float64), mean.to(torch.float64), std.to(torch.float64)]))
+    tot_w, acc, acc2 = 0.0, 0.0, 0.0
+    for w, mean, std in torch.stack(rows).cpu().tolist():      # (the reference's arithmetic, in Python doubles as there)
         if math.isnan(std):
             std = 0.0
         tot_w += w
@@ -143,7 +244,10 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
     g_norm_avg = torch.zeros((), device=data[0].device)
     iters_done = 0
     net.train()
-    for it in range(max_iters):
+    # the one-kernel optimiser step (Yogi on the GPU): parameters and gradients are views of flat buffers from here on
+    flat_g = optimizer.flat_grad() if hasattr(optimizer, "flat_grad") else None
+
+    def one_iteration():
         if oversampling:    # model.py:194-195: draw proportionally to the visit weights
             idx = torch.multinomial(train[-1].reshape(-1), batch_size, replacement=sample_replacement, generator=generator)
         elif sample_replacement:
@@ -156,20 +260,56 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
         loss, _ = loss_fn(net, [d[idx] for d in train], weighted)
         loss.backward()
         if world > 1:
-            grads = [p.grad for p in net.parameters() if p.grad is not None]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            tdist.all_reduce(flat, group=group)
-            flat /= world
-            off = 0
-            for g in grads:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+            if flat_g is not None:
+                tdist.all_reduce(flat_g, group=group)
+                flat_g.div_(world)
+            else:
+                grads = [p.grad for p in net.parameters() if p.grad is not None]
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                tdist.all_reduce(flat, group=group)
+                flat /= world
+                off = 0
+                for g in grads:
+                    g.copy_(flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
         # 2-norm over all parameter gradients (model.py:87-95), reported in the log line the dashboards parse
-        g_norm_avg += torch.sqrt(sum((p.grad.detach() ** 2).sum() for p in net.parameters() if p.grad is not None))
+        if flat_g is not None:
+            g_norm_avg.add_(torch.linalg.vector_norm(flat_g))
+        else:
+            g_norm_avg.add_(torch.sqrt(sum((p.grad.detach() ** 2).sum() for p in net.parameters() if p.grad is not None)))
         if grad_clip > 0:
             torch.nn.utils.clip_grad_norm_(net.parameters(), grad_clip)
         optimizer.step()
-        loss_avg += loss.detach()
+        loss_avg.add_(loss.detach())
+
+    # One iteration is a fixed sequence of launches (index draw, gather, forward, backward, the one-kernel step): after three
+    # of them it is captured in a HIP graph and replayed - the fit of a 478 342-parameter net on batches of 1 024 was bound by
+    # its launches, not by its arithmetic (r05: 2.3 ms an iteration for 0.1 ms of matrix work).  Not with more than one rank
+    # (the all-reduce stays outside), a sampling stream of the caller's, or gradient clipping.
+    import os
+    graph, n_warm = None, 3
+    want_graph = (flat_g is not None and world == 1 and flat_g.is_cuda and generator is None and grad_clip <= 0 and not oversampling
+                  and sample_replacement and os.environ.get("TM_TRAIN_GRAPH", "1") != "0" and max_iters > n_warm)
+    it = 0
+    while it < max_iters:
+        if want_graph and graph is None and it == n_warm:
+            try:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                t_before = optimizer._flat["t"]
+                with torch.cuda.graph(graph):
+                    one_iteration()
+                optimizer._flat["t"] = t_before          # (captured, not run)
+            except Exception as e:                        # noqa: BLE001 - whatever the runtime refuses: the eager loop is the same fit
+                graph, want_graph = None, False
+                torch.cuda.synchronize()
+                if log:
+                    print("train_data: no graph replay (%s: %s)" % (type(e).__name__, str(e).splitlines()[0][:120]), file=stderr, flush=True)
+        if graph is not None:
+            graph.replay()
+            optimizer._flat["t"] += 1
+        else:
+            one_iteration()
         iters_done = it + 1
         if (it + 1) % iters_per_val == 0 and val is not None:
             net.eval()
@@ -198,9 +338,12 @@ def train_data(net, optimizer, data, batch_size=128, iters_per_val=500, validati
             g_norm_avg.zero_()
             if early_stopping and fails >= early_stopping_patience:
                 break
+        it += 1
+    replayed = graph is not None
+    del graph
     if early_stopping and load and best < float("inf"):
         load()
     elif save:
         save()
     net.eval()
-    return dict(iters=iters_done, best_validation=best)
+    return dict(iters=iters_done, best_validation=best, graph_replay=replayed)
