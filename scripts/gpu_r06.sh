@@ -1,69 +1,112 @@
 #!/bin/bash
-# Round-6 GPU calls (one gpurun call each): scripts/gpu_r06.sh <part> [...]
-#   gc       smoke + the parity tests that go through collections (the sweep marker's gate), first failure stops
-#   gcq      the quick version of gc
-#   steady   the steady-state windows (random-init and trained net), no CPU legs: ms/move, waiting launches, catch-up launches
-#   suite    the whole -m gpu suite as the driver runs it + smoke
+# Round-6 GPU calls, one script: scripts/gpu_r06.sh <part> [...]   (each part is one `gpurun` call's worth; output under gpurun_out/r06.*,
+# the files that are evidence are copied to profiles/r06_* afterwards)
+#   gcq      the quick gate of a collector change: smoke, the collector tests, the benched-regime tests that live on collections
+#   gc       every parity test that goes through collections
+#   suite    the whole -m gpu suite as the driver runs it (one serial process) + smoke
+#   new      this round's new tests (fused Yogi, graph-replayed fit, hand-off stress), then the headline window's kernels
+#   steady   the two steady-state windows (moves 76-95; random-init and trained net): ms/move, waiting launches, catch-up launches
+#   sweep    collector parameters on both steady-state windows: marking allowance, speculative threshold
+#   tune     trained net: marking allowance x cost allowance, with the tree kernel's time per launch
 #   bench    the driver's command line
+#   prof     rocprofv3 kernel traces (headline window, both steady-state windows) and the PMC passes of the headline window
+#   lp dist  BASELINE configs[2] / configs[4]: bench line + kernel trace
+#   online   the online self-play run (ValueSimLP, 512 games x 200 sims, fits every 50 moves), MIN minutes (default 11)
+#   evalck   a checkpoint's play strength (same protocol, no training), MIN minutes (default 9), CKPT=<file>
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 CK=tetris_mcts_amd/checkpoints/value_net_online_r05.pt
-steady_line() { python - "$1" <<'PY'
+HEAD="--no-cpu-baseline --steady-steps 0 --others none"
+line() { python - "$1" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-for name, w in (("head", d), ("steady", d.get("steady_state"))):
-    if not w: continue
-    print(name, {k: w.get(k) for k in ("value", "ms_per_step", "gc", "tree_kernel_ms", "value_net_ms")})
+g = d["gc"]
+print(sys.argv[1].split("/")[-1], "%.2f M/s %.2f ms/move" % (d["value"] / 1e6, d["ms_per_step"]),
+      "| %s %.4f ms frac %.3f | %s %.4f ms frac %.3f" % (d["roofline"]["kernel"][:12], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"],
+                                                       d["roofline_other"]["kernel"][:12], d["roofline_other"]["avg_launch_ms"], d["roofline_other"]["frac"]),
+      "| collections %d waiting %.2f catch-up/move %.1f marker launches %.1f blocks %.0f" % (
+          g["collections"], g["launches_per_collection"] or 0, g["catchup_launches_per_move"], g["marker"]["launches_per_collection"] or 0,
+          g["marker"]["blocks_per_collection"] or 0))
 PY
+}
+prof_kt() {   # name, last, bench args...: per-kernel table of the last N launches
+  local name=$1 last=$2; shift 2
+  cd /tmp; rm -rf /tmp/p_$name
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -- python $R/bench.py "$@" > $R/$OUT/r06.$name.json 2> $R/$OUT/r06.$name.err; echo "$name kernel trace rc=$?"
+  cd $R; python scripts/kernel_stats.py /tmp/p_$name $OUT/r06.kernel_stats_$name.csv --last $last; head -n 5 $OUT/r06.kernel_stats_$name.csv | cut -c1-60,150-400
+}
+prof_pmc() {  # name, last, bench args...
+  local name=$1 last=$2; shift 2
+  cd /tmp; rm -rf /tmp/p_${name}_f /tmp/p_${name}_w
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_${name}_f -- python $R/bench.py "$@" > /dev/null 2> $R/$OUT/r06.${name}_fetch.err; echo "$name fetch rc=$?"
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_${name}_w -- python $R/bench.py "$@" > /dev/null 2> $R/$OUT/r06.${name}_write.err; echo "$name write rc=$?"
+  cd $R
+  KEY=$(python -c "import json;print(json.load(open('$OUT/r06.$name.json'))['config']['workload_key'])")
+  python scripts/pmc_traffic.py $OUT/r06.pmc_traffic_$name.json $OUT/r06.pmc_traffic_$name.csv /tmp/p_${name}_f /tmp/p_${name}_w --last $last --workload-key "$KEY" \
+    --command "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py $* (one pass per counter; averaged over the last $last launches of every kernel = the timed window)"
+  grep "k_sim_step\|k_vn_\|k_dn_" $OUT/r06.pmc_traffic_$name.csv
 }
 cd $R
 for p in "$@"; do case $p in
+gcq)
+  timeout 300 python __graft_entry__.py smoke > $OUT/r06.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/r06.smoke.log | cut -c1-300
+  ( time timeout 900 python -m pytest -x -q -m gpu tests/test_gpu_collector.py tests/test_gpu_benched_regime.py -k "collector or waiting or grid or catch_up or steady_state or trained or full_pool or under_load" > $OUT/r06.gcq_tests.log 2>&1 ) 2>&1 | grep real
+  tail -n 6 $OUT/r06.gcq_tests.log | cut -c1-220 ;;
 gc)
   timeout 300 python __graft_entry__.py smoke > $OUT/r06.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $OUT/r06.smoke.log | cut -c1-300
   ( time timeout 1500 python -m pytest -x -q -m gpu tests/test_gpu_tree.py tests/test_gpu_collector.py tests/test_gpu_benched_regime.py tests/test_gpu_dist_agent.py --durations=10 > $OUT/r06.gc_tests.log 2>&1 ) 2>&1 | grep real
   tail -n 30 $OUT/r06.gc_tests.log | cut -c1-220 ;;
-gcq)
-  # the quick gate: smoke, the collector tests, the benched-regime tests that live on collections
-  timeout 300 python __graft_entry__.py smoke > $OUT/r06.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/r06.smoke.log | cut -c1-300
-  ( time timeout 900 python -m pytest -x -q -m gpu tests/test_gpu_collector.py tests/test_gpu_benched_regime.py -k "collector or waiting or grid or catch_up or steady_state or trained or full_pool or under_load" > $OUT/r06.gcq_tests.log 2>&1 ) 2>&1 | grep real
-  tail -n 6 $OUT/r06.gcq_tests.log | cut -c1-220 ;;
-steady)
-  timeout 600 python bench.py --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 > $OUT/r06.steady_random.json 2> $OUT/r06.steady_random.err; echo "random rc=$?"
-  steady_line $OUT/r06.steady_random.json
-  timeout 600 python bench.py --checkpoint $CK --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 > $OUT/r06.steady_trained.json 2> $OUT/r06.steady_trained.err; echo "trained rc=$?"
-  steady_line $OUT/r06.steady_trained.json ;;
-sweep)
-  # collector parameters on both steady-state windows: marking allowance, speculative threshold
-  for sl in 60000 100000 150000 220000; do for net in random trained; do
-    ck=""; [ $net = trained ] && ck="--checkpoint $CK"
-    timeout 300 python bench.py $ck --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 --gc-slice-cycles $sl > $OUT/r06.sweep_slice${sl}_$net.json 2> /dev/null
-    python -c "import json;d=json.load(open('$OUT/r06.sweep_slice${sl}_$net.json'));print('slice',$sl,'$net',round(d['ms_per_step'],2),round(d['gc']['launches_per_collection'],2),d['gc']['catchup_launches_per_move'])"
-  done; done
-  for sp in 128 512 1024; do for net in random trained; do
-    ck=""; [ $net = trained ] && ck="--checkpoint $CK"
-    timeout 300 python bench.py $ck --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 --gc-spec-nodes $sp > $OUT/r06.sweep_spec${sp}_$net.json 2> /dev/null
-    python -c "import json;d=json.load(open('$OUT/r06.sweep_spec${sp}_$net.json'));print('spec',$sp,'$net',round(d['ms_per_step'],2),round(d['gc']['launches_per_collection'],2),d['gc']['catchup_launches_per_move'])"
-  done; done ;;
-tune)
-  # trained-net steady state: marking allowance x cost allowance
-  for cfg in "120000 0" "135000 0" "150000 8" "150000 16" "135000 16" "170000 0"; do set -- $cfg
-    timeout 300 python bench.py --checkpoint $CK --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 --gc-slice-cycles $1 --gc-cost-units $2 > $OUT/r06.tune_$1_$2.json 2> /dev/null
-    python -c "import json;d=json.load(open('$OUT/r06.tune_$1_$2.json'));print('slice',$1,'cost',$2,round(d['ms_per_step'],2),'tree',round(d['roofline']['avg_launch_ms'],4),'waiting',round(d['gc']['launches_per_collection'],2),'catch-up',d['gc']['catchup_launches_per_move'])"
-  done ;;
-stop)
-  # when the marking of a launch ends: sixteenths of the simulation workgroups finished (tree.hip GC_STOP_DONE_16THS), built on the box
-  for th in 4 8 12; do
-    bash scripts/build_variant.sh stop$th "s/^constexpr int GC_STOP_DONE_16THS = [0-9]*;/constexpr int GC_STOP_DONE_16THS = $th;/" > /dev/null
-    for net in random trained; do
-      ck=""; [ $net = trained ] && ck="--checkpoint $CK"
-      TETRIS_MCTS_LIB=$R/build_variants/stop$th.so timeout 300 python bench.py $ck --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 > $OUT/r06.stop${th}_$net.json 2> /dev/null
-      python -c "import json;d=json.load(open('$OUT/r06.stop${th}_$net.json'));print('stop at',$th,'/16','$net',round(d['ms_per_step'],2),round(d['gc']['launches_per_collection'],2),d['gc']['catchup_launches_per_move'])"
-    done; done ;;
 suite)
   ( time timeout 1700 python -m pytest tests -m gpu -q --durations=15 > $OUT/r06.pytest.log 2>&1 ) 2>&1 | grep real
   tail -n 24 $OUT/r06.pytest.log | cut -c1-200
   timeout 300 python __graft_entry__.py smoke > $OUT/r06.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/r06.smoke.log | cut -c1-300 ;;
+new)
+  ( time timeout 900 python -m pytest -x -q -m gpu tests/test_gpu_train_dist.py tests/test_gpu_valuenet.py tests/test_gpu_dist_agent.py tests/test_gpu_tree.py -k "yogi or fit or training or stress or valuenet or head or online_training_loop" --durations=8 > $OUT/r06.new_tests.log 2>&1 ) 2>&1 | grep real
+  tail -n 16 $OUT/r06.new_tests.log | cut -c1-220
+  timeout 300 python bench.py $HEAD > $OUT/r06.head.json 2> $OUT/r06.head.err; echo "head rc=$?"; line $OUT/r06.head.json ;;
+steady)
+  timeout 600 python bench.py --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 > $OUT/r06.steady_random.json 2> $OUT/r06.steady_random.err; echo "random rc=$?"
+  line $OUT/r06.steady_random.json
+  timeout 600 python bench.py --checkpoint $CK --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 > $OUT/r06.steady_trained.json 2> $OUT/r06.steady_trained.err; echo "trained rc=$?"
+  line $OUT/r06.steady_trained.json ;;
+sweep)
+  for sl in 60000 100000 150000 220000; do for net in random trained; do
+    ck=""; [ $net = trained ] && ck="--checkpoint $CK"
+    timeout 300 python bench.py $ck --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 --gc-slice-cycles $sl > $OUT/r06.sweep_slice${sl}_$net.json 2> /dev/null
+    line $OUT/r06.sweep_slice${sl}_$net.json
+  done; done
+  for sp in 128 512 1024; do for net in random trained; do
+    ck=""; [ $net = trained ] && ck="--checkpoint $CK"
+    timeout 300 python bench.py $ck --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 --gc-spec-nodes $sp > $OUT/r06.sweep_spec${sp}_$net.json 2> /dev/null
+    line $OUT/r06.sweep_spec${sp}_$net.json
+  done; done ;;
+tune)
+  for cfg in "120000 0" "135000 0" "150000 8" "150000 16" "135000 16" "170000 0"; do set -- $cfg
+    timeout 300 python bench.py --checkpoint $CK --no-cpu-baseline --others none --warmup 75 --steps 20 --steady-steps 0 --gc-slice-cycles $1 --gc-cost-units $2 > $OUT/r06.tune_$1_$2.json 2> /dev/null
+    line $OUT/r06.tune_$1_$2.json
+  done ;;
 bench)
   ( time timeout 900 python bench.py > $OUT/r06.bench.json 2> $OUT/r06.bench.err ) 2>&1 | grep real
-  steady_line $OUT/r06.bench.json ;;
+  line $OUT/r06.bench.json
+  python -c "import json;d=json.load(open('$OUT/r06.bench.json'));print({k:v for k,v in d.items() if not isinstance(v,(dict,list))})" ;;
+prof)
+  prof_kt head 10000 $HEAD
+  prof_pmc head 10000 $HEAD
+  prof_kt steady_random 10000 --no-cpu-baseline --steady-steps 0 --others none --warmup 75 --steps 20
+  prof_kt steady_trained 10000 --checkpoint $CK --no-cpu-baseline --steady-steps 0 --others none --warmup 75 --steps 20 ;;
+lp)
+  prof_kt lp 10000 --agent ValueSimLP $HEAD; line $OUT/r06.lp.json ;;
+dist)
+  prof_kt dist 5000 --agent DistValueSim --sims 1000 --warmup 2 --steps 5 $HEAD; line $OUT/r06.dist.json ;;
+online)
+  MIN=${MIN:-11}
+  timeout $((MIN*60+120)) python scripts/selfplay_online.py --minutes $MIN --max-nodes 100000 --games 512 --sims 200 --train-every 50 \
+     --out $OUT/r06.online_learning.jsonl --save $OUT/r06.checkpoint.pt > $OUT/r06.online.log 2>&1; echo "online rc=$?"
+  tail -n 2 $OUT/r06.online.log | cut -c1-900; ls -la $OUT/r06.checkpoint.pt ;;
+evalck)
+  MIN=${MIN:-9}; CKPT=${CKPT:-$CK}
+  timeout $((MIN*60+120)) python scripts/selfplay_online.py --minutes $MIN --max-nodes 100000 --games 512 --sims 200 --train-every 250 \
+     --load $CKPT --no-train --out $OUT/r06.checkpoint_play.jsonl > $OUT/r06.checkpoint_play.log 2>&1; echo "rc=$?"
+  tail -n 1 $OUT/r06.checkpoint_play.log | cut -c1-600 ;;
+*) echo "unknown part $p" ;;
 esac; done
