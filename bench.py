@@ -526,7 +526,7 @@ def main():
     ck = os.path.join(ROOT, TRAINED_CHECKPOINT)
     if want_others and os.path.isfile(ck):
         # the metric's second half: the headline's own windows (moves 6-25 and 76-95 of 4096 games x 500 simulations) under a value
-        # net that this engine's online self-play trained (scripts/gpu_r05_train.sh; profiles/r05_online_learning*.jsonl is its
+        # net that this engine's online self-play trained (scripts/gpu_r06.sh online; profiles/r0[56]_online_learning*.jsonl is its
         # learning curve) - throughput under narrower, deeper-valued trees, and the lines the search clears with it
         try:
             line, tmodel = run_agent(args, "ValueSim", sims, args.warmup, args.steps, args.steady_warmup, args.steady_steps, ctx, checkpoint=ck)
@@ -546,6 +546,9 @@ def main():
         # the other lines' headline numbers as scalars of the line itself (a reader that keeps only top-level scalars keeps them)
         if "steady_state" in out:
             out["steady_value"], out["steady_ms_per_step"] = out["steady_state"]["value"], out["steady_state"]["ms_per_step"]
+            sg = out["steady_state"].get("gc") or {}
+            out["steady_waiting_launches_per_collection"] = sg.get("launches_per_collection")
+            out["steady_catchup_launches_per_move"] = sg.get("catchup_launches_per_move")
         for key, name in (("lp", "ValueSimLP"), ("dist", "DistValueSim"), ("vanilla", "Vanilla")):
             if "value" in others.get(name, {}):
                 out[key + "_value"], out[key + "_ms_per_step"] = others[name]["value"], others[name]["ms_per_step"]
@@ -554,6 +557,10 @@ def main():
             out["trained_mean_trace_len"] = trained["mean_trace_len"]
             out["trained_lines_per_1000_moves"] = trained["lines_per_1000_moves"]
             if "steady_state" in trained:
+                out["trained_steady_value"], out["trained_steady_ms_per_step"] = trained["steady_state"]["value"], trained["steady_state"]["ms_per_step"]
+                tg = trained["steady_state"].get("gc") or {}
+                out["trained_steady_waiting_launches_per_collection"] = tg.get("launches_per_collection")
+                out["trained_steady_catchup_launches_per_move"] = tg.get("catchup_launches_per_move")
                 out["trained_steady_lines_per_1000_moves"] = trained["steady_state"]["lines_per_1000_moves"]
                 out["trained_steady_mean_lines_all_episodes_under_way"] = trained["steady_state"]["mean_lines_all_episodes_under_way"]
         if others:

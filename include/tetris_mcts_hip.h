@@ -263,6 +263,9 @@ int tm_gc_step(const tm_store *s, void *stream);
                                 not a leaf whose observation was evaluated under the current weights (s->obs_eval).  Results
                                 are identical either way; a Python evaluator callable keeps receiving all k children
                                 (agent.cpp:424-436), so the Python-driven loop does not set it */
+#define TM_SIM_GC_MEM_MARKS 16 /* the collector workgroups keep their mark bitmaps in memory whatever the pool's size (the form pools of
+                                  more than 100 000 nodes take, tree.hip gc_marks_in_lds); set by tm_sim_step / tm_gc_step themselves when
+                                  TM_GC_MARKS_IN_MEMORY=1 is in the environment (tests) */
 int tm_sim_step(const tm_store *s, int flags, void *stream);
 int tm_eval_render(const tm_store *s, int8_t *out /* [G*eval_slots][200] */, void *stream);
 

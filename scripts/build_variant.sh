@@ -1,16 +1,18 @@
 #!/bin/bash
-# build_variants/<name>.so: the library with other values of tree.hip's tuning constants (measurements only; runs where hipcc is)
-# usage: scripts/build_variant.sh NAME 'sed-expression' ['sed-expression' ...]      then: TETRIS_MCTS_LIB=build_variants/NAME.so python bench.py ...
+# build_variants/<name>.so: the library with one source file edited by sed expressions (measurements only; runs where hipcc is)
+# usage: scripts/build_variant.sh NAME FILE 'sed-expression' ['sed-expression' ...]     FILE: tree.hip | valuenet.hip | valuenet_conv.inc | distnet.hip
+# then:  TETRIS_MCTS_LIB=$PWD/build_variants/NAME.so python bench.py ...
 set -e
-NAME=$1; shift
+NAME=$1; FILE=$2; shift 2
 cd "$(dirname "$0")/.."
-mkdir -p build_variants /tmp/tmv_$NAME
-cp tetris_mcts_amd/csrc/tree.hip /tmp/tmv_$NAME/tree.hip
-for e in "$@"; do sed -i -e "$e" /tmp/tmv_$NAME/tree.hip; done
-if cmp -s tetris_mcts_amd/csrc/tree.hip /tmp/tmv_$NAME/tree.hip; then echo "build_variant $NAME: no expression matched"; exit 1; fi
-sed -i 's#"../../include/tetris_mcts_hip.h"#"'$PWD'/include/tetris_mcts_hip.h"#' /tmp/tmv_$NAME/tree.hip
-cp tetris_mcts_amd/csrc/*.h tetris_mcts_amd/csrc/*.inc /tmp/tmv_$NAME/ 2>/dev/null || true
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c /tmp/tmv_$NAME/tree.hip -o /tmp/tmv_$NAME/tree.o
-O=tetris_mcts_amd/csrc/_obj
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/tmv_$NAME/tree.o $O/search.o $O/core_api.o $O/valuenet.o $O/distnet.o $O/yogi.o -o build_variants/$NAME.so
+D=/tmp/tmv_$NAME; rm -rf $D; mkdir -p build_variants $D
+cp tetris_mcts_amd/csrc/*.hip tetris_mcts_amd/csrc/*.h tetris_mcts_amd/csrc/*.inc $D/
+for e in "$@"; do sed -i -e "$e" $D/$FILE; done
+if cmp -s tetris_mcts_amd/csrc/$FILE $D/$FILE; then echo "build_variant $NAME: no expression matched in $FILE"; exit 1; fi
+sed -i 's#"../../include/tetris_mcts_hip.h"#"'$PWD'/include/tetris_mcts_hip.h"#' $D/*.hip
+SRC=$FILE; [ $FILE = valuenet_conv.inc ] && SRC=valuenet.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c $D/$SRC -o $D/variant.o
+O=tetris_mcts_amd/csrc/_obj; OBJS=""
+for s in tree core_api valuenet distnet search yogi; do if [ $s.hip = $SRC ]; then OBJS="$OBJS $D/variant.o"; else OBJS="$OBJS $O/$s.o"; fi; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o build_variants/$NAME.so
 echo "build_variants/$NAME.so"

@@ -57,7 +57,8 @@ gc)
   ( time timeout 1500 python -m pytest -x -q -m gpu tests/test_gpu_tree.py tests/test_gpu_collector.py tests/test_gpu_benched_regime.py tests/test_gpu_dist_agent.py --durations=10 > $OUT/r06.gc_tests.log 2>&1 ) 2>&1 | grep real
   tail -n 30 $OUT/r06.gc_tests.log | cut -c1-220 ;;
 suite)
-  ( time timeout 1700 python -m pytest tests -m gpu -q --durations=15 > $OUT/r06.pytest.log 2>&1 ) 2>&1 | grep real
+  # (TM_TEST_FULL=1: the online training-set parity replays all 900 reference moves under all four policies - the driver's run: two of them)
+  ( time TM_TEST_FULL=1 timeout 1700 python -m pytest tests -m gpu -q --durations=15 > $OUT/r06.pytest.log 2>&1 ) 2>&1 | grep real
   tail -n 24 $OUT/r06.pytest.log | cut -c1-200
   timeout 300 python __graft_entry__.py smoke > $OUT/r06.smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/r06.smoke.log | cut -c1-300 ;;
 new)
@@ -98,6 +99,20 @@ lp)
   prof_kt lp 10000 --agent ValueSimLP $HEAD; line $OUT/r06.lp.json ;;
 dist)
   prof_kt dist 5000 --agent DistValueSim --sims 1000 --warmup 2 --steps 5 $HEAD; line $OUT/r06.dist.json ;;
+ldsprobe)
+  # the LDS bank conflicts of k_vn_conv's conv2 reads, MEASURED by removing them: a variant whose reads go to pitch-6 addresses
+  # (32 consecutive floats a half-wave: conflict-free; the results are wrong, the instruction stream is the same) against the product,
+  # same inputs: kernel time and SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+  bash scripts/build_variant.sh conv_nc valuenet_conv.inc 's/boff2\[t\]\[j\] = y \* 8 + x + koff2\[j\];/boff2[t][j] = y * 6 + x + koff2[j];/' | tail -n 1
+  for lib in product conv_nc; do for B in 1867 7169; do
+    L=""; [ $lib != product ] && L=$R/build_variants/$lib.so
+    cd /tmp; rm -rf /tmp/pp_k /tmp/pp_c
+    TETRIS_MCTS_LIB=$L timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp_k -- python $R/scripts/conv_probe.py $B 200 > $R/$OUT/r06.ldsprobe_${lib}_$B.log 2>&1
+    TETRIS_MCTS_LIB=$L timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/pp_c -- python $R/scripts/conv_probe.py $B 50 > /dev/null 2>&1
+    cd $R; python scripts/kernel_stats.py /tmp/pp_k $OUT/r06.ldsprobe_ks_${lib}_$B.csv --last 150 > /dev/null
+    python scripts/pmc_traffic.py $OUT/r06.ldsprobe_pmc_${lib}_$B.json $OUT/r06.ldsprobe_pmc_${lib}_$B.csv /tmp/pp_c --last 40 --workload-key "conv_probe $B" --command "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -- python scripts/conv_probe.py $B 50 (raw counter sums per dispatch)" > /dev/null
+    echo "== $lib B=$B"; grep "k_vn_" $OUT/r06.ldsprobe_ks_${lib}_$B.csv | cut -c1-40,150-260; grep "k_vn_conv" $OUT/r06.ldsprobe_pmc_${lib}_$B.csv | cut -c1-300
+  done; done ;;
 online)
   MIN=${MIN:-11}
   timeout $((MIN*60+120)) python scripts/selfplay_online.py --minutes $MIN --max-nodes 100000 --games 512 --sims 200 --train-every 50 \

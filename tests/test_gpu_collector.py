@@ -123,3 +123,15 @@ def test_catch_up_over_the_owing_games_equals_catch_up_over_all_games():
     ss = native.store.search_stats(native.n_sub, native.ev_every, reset=False)
     assert native.store.counter("N_GC") == python.store.counter("N_GC") >= G
     assert ss["catchup_launches"] > 0 and ss["catchup_waves"] < 0.5 * G * ss["catchup_launches"]
+
+
+def test_marker_with_the_bitmaps_in_memory(oracle, monkeypatch):
+    """Pools of more than 100 000 nodes do not fit the marking workgroups' LDS: the marker then keeps its three bitmaps in memory
+    (tree.hip gc_sweep_mark<false>: the same sweeps on device-scope atomics).  TM_GC_MARKS_IN_MEMORY=1 makes every launch take
+    that form, so that it can be held to the oracle on pools the oracle replays in seconds: six games with one marking workgroup
+    between them, and forty games with five (several owners per game, cross-share sends), every move of every game, trees
+    included, through their collections."""
+    from test_gpu_tree import _compare_run
+    monkeypatch.setenv("TM_GC_MARKS_IN_MEMORY", "1")
+    assert _compare_run(oracle, "ValueSim", G=6, sims=40, max_nodes=8000, seed=11, moves=110, evaluator="hash", check_tree_every=25) >= 1
+    assert _compare_run(oracle, "ValueSimLP", G=40, sims=30, max_nodes=3000, seed=5, moves=50, evaluator="hash", check_tree_every=25) >= 10

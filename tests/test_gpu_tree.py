@@ -417,8 +417,10 @@ def test_online_cpp_agent_training_sets(oracle, golden_dir, idx):
     mem = ro.OnlineMemory(r["policy"], r["memory_size"], r["episodes_per_train"], r["growth"])
     seen, n_gc = 0, 0
     # (policies 0 and 3 - one episode-driven, one memory-driven - replay the reference's whole 900-move run; 1 and 2 its first
-    # 500 moves: three to four trainings each, at half the suite time)
-    n_moves = len(r["actions"]) if r["policy"] in (0, 3) else 500
+    # 500 moves: three to four trainings each, at half the suite time.  TM_TEST_FULL=1 - the round's evidence run, scripts/gpu_r06.sh
+    # suite - replays all 900 moves under every policy: >= 7 collections and >= 4 trainings each)
+    full = os.environ.get("TM_TEST_FULL", "0") == "1"
+    n_moves = len(r["actions"]) if (full or r["policy"] in (0, 3)) else 500
     for m, act in enumerate(r["actions"][:n_moves]):
         move[0] = m
         got = agent.play()

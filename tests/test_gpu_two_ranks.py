@@ -83,9 +83,18 @@ def _worker(rank, world, port, q):
     gen = torch.Generator(device="cuda").manual_seed(99)
     res = agent.model.train_data(list(data), batch_size=256, iters_per_val=4, max_iters=8, generator=gen, log=False)
     flat = agent.model.flat_params().cpu().numpy()
-    q.put((rank, acts, stats, tuples, info, flat, res["iters"]))
+    # (d) the distributional agent's exchange (dist.all_gather_rows: packed observation, distribution, visits) on DEVICE tensors,
+    # staged through host memory by the gloo group; the second call with a rank that has harvested nothing
+    rows = [tuple(c.cpu().numpy() for c in tdist.all_gather_rows(*_dist_rows(rank, n))) for n in (5 + 3 * rank, 4 * rank)]
+    q.put((rank, acts, stats, tuples, info, flat, res["iters"], rows))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _dist_rows(rank, n):
+    g = torch.Generator().manual_seed(1000 + rank)
+    return (torch.randint(-2 ** 31, 2 ** 31 - 1, (n, 12), generator=g, dtype=torch.int64).to(torch.int32).cuda(),
+            torch.rand(n, 64, generator=g).cuda(), torch.rand(n, generator=g).cuda())
 
 
 def _rows_sorted(a):
@@ -128,6 +137,12 @@ def test_two_ranks_on_one_gpu_equal_the_single_rank_job():
     assert n_tuples > 1000
     # (c) the replicas took the same steps
     assert res[0][6] == res[1][6] == 8 and res[0][5].tobytes() == res[1][5].tobytes()
+    # (d) rows of three columns, rank after rank, the same on both ranks - also when rank 0 has none
+    for call, sizes in enumerate(((5, 8), (0, 4))):
+        want = [np.concatenate([_dist_rows(r, n)[c].cpu().numpy() for r, n in enumerate(sizes)]) for c in range(3)]
+        for r in res:
+            for c in range(3):
+                assert r[7][call][c].dtype == want[c].dtype and r[7][call][c].tobytes() == want[c].tobytes(), (call, r[0], c)
     m0 = __import__("tetris_mcts_amd.model", fromlist=["Model_VV"]).Model_VV(backend="hip", seed=0)
     assert np.abs(res[0][5] - m0.flat_params().cpu().numpy()).max() > 1e-4           # ... and they did move
 

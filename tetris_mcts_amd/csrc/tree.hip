@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <atomic>
+#include <stdlib.h>
 #include "engine.h"
 #include "../../include/tetris_mcts_hip.h"
 
@@ -2581,7 +2582,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         }
     };
     if (tid < n_list && M.list_parts[tid] != 0 && M.list_part[tid] < 0 && !M.list_mark[tid]) arrive(tid, false);
-    const bool marks_in_lds = gc_marks_in_lds(N);
+    const bool marks_in_lds = gc_marks_in_lds(N) && !(flags & TM_SIM_GC_MEM_MARKS);
     for (int e = 0; e < M.n_order; ++e) {
         const int k = __builtin_amdgcn_readfirstlane((int)M.order[e]);
         const int g = __builtin_amdgcn_readfirstlane(M.list_g[k]), ph = __builtin_amdgcn_readfirstlane(M.list_step[k]);
@@ -3234,6 +3235,13 @@ using namespace tmcts;
 #define TM_LAUNCH_CHECK() ((int)hipGetLastError())
 static std::atomic<unsigned> tm_launch_seq{0};
 
+// TM_GC_MARKS_IN_MEMORY=1 in the environment: every launch's collectors keep their bitmaps in memory (what pools of more than
+// 100 000 nodes get) - so that a test can hold that form to the oracle on a pool the oracle replays in seconds
+static int gc_mem_marks_flag() {
+    const char* e = getenv("TM_GC_MARKS_IN_MEMORY");
+    return (e && e[0] == '1') ? TM_SIM_GC_MEM_MARKS : 0;
+}
+
 extern "C" {
 
 const char* tm_version(void) { return "tetris_mcts_hip 0.1 (gfx950)"; }
@@ -3308,7 +3316,7 @@ int tm_sim_step(const tm_store* s, int flags, void* stream) {
     if (s->game_list && (s->n_listed < 0 || s->n_listed > s->n_games)) return (int)hipErrorInvalidValue;
     // the launch number (bits 8.. of the kernel's flags): what orders a game's wave and its collector workgroup, which
     // only ever hand over at kernel boundaries.  Any two launches that touch the same game differ in it.
-    flags = (flags & 0xFF) | (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
+    flags = (flags & 0xFF) | (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8) | gc_mem_marks_flag();
     const int n_waves = s->game_list ? s->n_listed : s->n_games;       // simulation waves; the collectors are those of all n_games
     const dim3 grid((n_waves + WPB - 1) / WPB + gc_blocks(*s)), block(64 * WPB);
     if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
@@ -3319,7 +3327,7 @@ int tm_sim_step(const tm_store* s, int flags, void* stream) {
 }
 int tm_gc_step(const tm_store* s, void* stream) {
     // the collector workgroups alone, no time limit: one step of every collection under way
-    const int flags = TM_SIM_GC_FULL | (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8);
+    const int flags = TM_SIM_GC_FULL | (int)(((tm_launch_seq.fetch_add(1) + 1u) & 0x7FFFFu) << 8) | gc_mem_marks_flag();
     const dim3 grid(gc_blocks(*s)), block(64 * WPB);
     if (s->kind == TM_KIND_VANILLA || s->kind == TM_KIND_VANILLA_C)
         hipLaunchKernelGGL(k_sim_step<true>, grid, block, sim_lds_bytes(*s, true), (hipStream_t)stream, *s, flags);
