@@ -105,7 +105,7 @@ ldsprobe)
   # same inputs: kernel time and SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
   bash scripts/build_variant.sh conv_nc valuenet_conv.inc 's/boff2\[t\]\[j\] = y \* 8 + x + koff2\[j\];/boff2[t][j] = y * 6 + x + koff2[j];/' | tail -n 1
   for lib in product conv_nc; do for B in 1867 7169; do
-    L=""; [ $lib != product ] && L=$R/build_variants/$lib.so
+    L=$R/tetris_mcts_amd/libtetris_mcts_hip.so; [ $lib != product ] && L=$R/build_variants/$lib.so
     cd /tmp; rm -rf /tmp/pp_k /tmp/pp_c
     TETRIS_MCTS_LIB=$L timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp_k -- python $R/scripts/conv_probe.py $B 200 > $R/$OUT/r06.ldsprobe_${lib}_$B.log 2>&1
     TETRIS_MCTS_LIB=$L timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/pp_c -- python $R/scripts/conv_probe.py $B 50 > /dev/null 2>&1

@@ -134,4 +134,4 @@ def test_marker_with_the_bitmaps_in_memory(oracle, monkeypatch):
     from test_gpu_tree import _compare_run
     monkeypatch.setenv("TM_GC_MARKS_IN_MEMORY", "1")
     assert _compare_run(oracle, "ValueSim", G=6, sims=40, max_nodes=8000, seed=11, moves=110, evaluator="hash", check_tree_every=25) >= 1
-    assert _compare_run(oracle, "ValueSimLP", G=40, sims=30, max_nodes=3000, seed=5, moves=50, evaluator="hash", check_tree_every=25) >= 10
+    assert _compare_run(oracle, "ValueSimLP", G=40, sims=30, max_nodes=6000, seed=5, moves=90, evaluator="hash", check_tree_every=30) >= 10
