@@ -63,9 +63,10 @@ enum {
     TM_GS_FIRST_MISS = 28, /* levels of the last walk that were taken over from the walk before it (verified in parallel, tree.hip) */
     TM_GS_PREFIX_SUM,      /* sum of TM_GS_FIRST_MISS over all simulations */
     /* garbage collection by the collector workgroups of tm_sim_step (a game that collects does not simulate; tree.hip) */
-    TM_GS_GC_PHASE = 32, /* 0 none; (launch << 4) | 1 requested; 2 marking, 3 counting, 4 writing the free lists, 5 / 6 re-inserting nodes /
-                            observations; (launch << 4) | 7 complete (the game resumes in a later launch); speculative marking while the
-                            game simulates: (launch << 4) | 8 requested, 9 under way, (launch << 4) | 10 the pool ran dry meanwhile */
+    TM_GS_GC_PHASE = 32, /* 0 none; (launch << 4) | 1 requested; 2 marking, 3 counting + re-inserting the kept nodes, 4 writing the free
+                            lists + re-inserting the kept observations; (launch << 4) | 7 complete (the game resumes in a later
+                            launch); speculative marking while the game simulates: (launch << 4) | 8 requested, 9 under way,
+                            (launch << 4) | 10 the pool ran dry meanwhile */
     TM_GS_GC_ARRIVE,     /* collector workgroups that have done their share of the current step (bits 8..: some left work) */
     TM_GS_GC_RSV0, TM_GS_GC_RSV1, /* (unused) */
     TM_GS_GC_WORK,       /* marking: chunks were flagged when the last launch that looked ended (the next one marks) */
@@ -206,9 +207,9 @@ typedef struct tm_store {
        collector workgroups look after all n_games as always.  NULL: every game (wave i = game i).  Filled by tm_sims_owing. */
     const int32_t *game_list;
     int32_t n_listed;
-    int32_t gc_cost_units; /* cost units of bounded collection steps (init / count 1, write 2, re-insertion of nodes / observations 5
-                              each: about 5 microseconds a unit) the collector workgroups of one tm_sim_step launch take on; 0: the
-                              default (12).  More units serve more collections per launch and make the launch longer. */
+    int32_t gc_cost_units; /* cost units of bounded collection steps (init 1, count + re-insertion of the nodes 6, write + re-insertion of
+                              the observations 7: about 5 microseconds a unit) the collector workgroups of one tm_sim_step launch take
+                              on; 0: the default (13).  More units serve more collections per launch and make the launch longer. */
     int32_t gc_collectors; /* collector workgroups per tm_sim_step launch (half for the bounded steps, half for the marking); 0: the
                               default (128), at most 128.  A collection must be continued by launches with the same number. */
 } tm_store;

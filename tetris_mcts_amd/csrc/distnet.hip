@@ -175,11 +175,8 @@ __global__ __launch_bounds__(256, 2) void k_dn_conv(const float* __restrict__ P,
     const float4* W2 = reinterpret_cast<const float4*>(prep + PREP_W2) + lane;
 
     // the two dependent global reads per request (request -> packed game) are issued one state ahead
-    // (as k_vn_conv: a full grid deals the positions by XCD - k_dn_fc's tile t, 16 positions, runs on XCD t % 8, and its rows
-    // are written there: workgroup b = (XCD b % 8, its q-th: b / 8) takes the positions 4 (q % 4) .. + 3 of tile b % 8 + 8 (q / 4))
     const int stride = gridDim.x * 4;
     int s = blockIdx.x * 4 + w;
-    if (gridDim.x == 512) { const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3; s = 16 * (xcd + 8 * (q >> 2)) + 4 * (q & 3) + w; }
     int o_next = (!states && s < n) ? eval_obs[s] : 0;
     uint32_t gw_next = 0;
     if (!states && s < n && lane < 16) gw_next = node_game[((size_t)s * max_nodes + o_next) * tmcts::GAME_DW + lane];

@@ -1895,10 +1895,11 @@ __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, i
 // All workgroups see the same games in the same steps: the control blocks they read were written in earlier launches.
 // A collection in progress must be continued by launches over the same range of games (same n).
 // ---------------------------------------------------------------------------------------------------
-constexpr int GCP_INIT = GC_REQ, GCP_MARK = 2, GCP_COUNT = 3, GCP_WRITE = 4, GCP_NODES = 5, GCP_OBS = 6;
+constexpr int GCP_INIT = GC_REQ, GCP_MARK = 2, GCP_COUNT = 3, GCP_WRITE = 4;      // (5, 6: the re-insertions' own steps until r06)
+constexpr int GCP_LAST = 6;
 constexpr int GC_LIST_MAX = 256, GC_LIST_WAIT = 64;     // collecting games looked after per launch (the others wait): all, and those that are waiting for their collection
-constexpr int GC_COST_MAX = 12;      // per launch: cost units of the steps whose shares are done without looking at the clock
-                                     // (init 1, count 1, write 2, nodes 5, observations 5: about 5 microseconds a unit)
+constexpr int GC_COST_MAX = 13;      // per launch: cost units of the steps whose shares are done without looking at the clock
+                                     // (init 1, count + nodes 6, write + observations 7: about 5 microseconds a unit; 13 = one of each)
 constexpr int GC_WL_WORDS = 16;       // the marker's work list: 512 units (a unit = a block for pools up to 131 072 nodes)
 struct GcLds {
     int scan[8];                     // Grp<256> scratch
@@ -2284,7 +2285,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
     auto classify = [&](int& word) -> int {       // 0: waiting for its collection, 1: speculative marking, -1: neither
         const int ph = word & 15;
         const bool now = (word >> 4) == seq;
-        if (ph >= GCP_MARK && ph <= GCP_OBS) return 0;
+        if (ph >= GCP_MARK && ph <= GCP_LAST) return 0;
         if (ph == GC_REQ) return now ? -1 : 0;
         if (ph == GC_SPEC_REQ) return now ? -1 : 1;
         if (ph == GC_SPEC_MARK) return 1;
@@ -2448,7 +2449,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         const int k = !in_plan ? 0 : p < n_wait ? (int)M.by_age[p] : n_wait + ((p - n_wait) + seq) % n_spec;
         const int step = in_plan ? M.list_step[k] : GC_FOREIGN;
         const bool bounded = in_plan && step != GC_FOREIGN && step != GC_IDLE && step != GCP_MARK;
-        const int cost = !bounded ? 0 : step == GCP_WRITE ? 2 : (step == GCP_NODES || step == GCP_OBS) ? 5 : 1;      // init / clear / count: 1
+        const int cost = !bounded ? 0 : step == GCP_WRITE ? 7 : step == GCP_COUNT ? 6 : 1;      // init / clear: 1; count + nodes: 1 + 5; write + observations: 2 + 5
         // 1. the entries with a bounded step, in the plan's order, and one thread's greedy pass over them
         int n_bd;
         const int bpos = G_::exscan(bounded ? 1 : 0, tid, sm, n_bd);
@@ -2572,10 +2573,7 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                 if (m0 + kf > S.replay_cap) gs[TM_GS_N_DROPPED] += m0 + kf - S.replay_cap;   // never silently (the reference keeps all up to memory_size)
                 S.replay_count[g] = min(S.replay_cap, m0 + kf);
             }
-            gs[TM_GS_GC_PHASE] = GCP_NODES;
-        } else if (step == GCP_NODES) {
-            gs[TM_GS_GC_PHASE] = GCP_OBS;
-        } else {      // GCP_OBS
+            // (the kept observations went back into their table in this launch, the kept nodes in the one before: complete)
             gs[TM_GS_N_GC] += 1;
             gs[TM_GS_GC_IN_MOVE] = 1;
             gs[TM_GS_GC_PHASE] = vreg((seq << 4) | GC_DONE);
@@ -2719,7 +2717,11 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                     if (o >= low_obs) *reinterpret_cast<uint4*>(P.stat() + (size_t)o * 4) = make_uint4(0, 0, 0, 0);
                 }
             }
-        } else if (ph == GCP_NODES) {
+        }
+        // The re-insertions ride along (r06): they read what the steps above do not write - the KEPT nodes' games and the cleared
+        // table with the count, the KEPT observations' keys with the write step (which clears and lists the FREED ones) - so a
+        // collection is two launches after its marking instead of four.
+        if (ph == GCP_COUNT) {
             // the kept nodes, by index (the bitmap says which), back into their (cleared) table: threads claim empty slots with a
             // 64-bit compare-and-swap (no deletions happen concurrently, so linear probing stays consistent; placement order
             // does not affect lookups)
@@ -2749,7 +2751,8 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
                     while (atomicCAS(reinterpret_cast<unsigned long long*>(&P.ntab()[sl]), 0ull, ent) != 0ull) sl = (sl + 1) & mask;
                 }
             }
-        } else if (S.kind != TM_KIND_DIST) {    // GCP_OBS (no observation table without the projection)
+        }
+        if (ph == GCP_WRITE && S.kind != TM_KIND_DIST) {    // (no observation table without the projection)
             constexpr int UR = 2;
             {
                 const int lo = (int)((long long)N * p0 / n_parts), hi = (int)((long long)N * p1 / n_parts);

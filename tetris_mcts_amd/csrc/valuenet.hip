@@ -490,7 +490,7 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     int blocks = (n + 3) / 4;
     if (blocks > 256 * CONV_WG_PER_CU) blocks = 256 * CONV_WG_PER_CU;   // resident workgroups, waves stride over the states
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, rq,
-                       max_nodes, n, scratch, SS, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, n >= 8192 ? 64 : 32);
+                       max_nodes, n, scratch, SS, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS);
     if (n >= 8192)      // (request slots: the leaf-parallel kinds' seven per game)
         hipLaunchKernelGGL((k_vn_fc1<4, 4, 128, 3>), dim3((n + 63) / 64, 4), dim3(512), 0, stream, P, prepared, scratch, SS, n,
                            scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 64 * SS, v, var);
