@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STATE = 3803136            # conv1 82,944 + conv2 1,769,472 + conv3 1,032,192 + fc1 917,504 + fc_out 1,024
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak
-PMC_FILE = os.path.join("profiles", "r0[45]_pmc_traffic*.json")   # one file per profiled command line (workload_key); the latest round's wins
+PMC_FILE = os.path.join("profiles", "r0[456]_pmc_traffic*.json")   # one file per profiled command line (workload_key); the latest round's wins
 
 
 def pmc_traffic(kernels, workload_key, fetch_scale=1.0):
@@ -316,7 +316,7 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx,
             "workload_key": workload_key,
             "games_per_gpu": G, "sims_per_move": sims, "agent": name, "max_nodes": max_nodes,
             "valuenet_backend": None if is_vanilla else args.backend, "sub_batches": NS, "online": bool(args.online),
-            "gc_slice_cycles": args.gc_slice_cycles, "gc_spec_nodes": args.gc_spec_nodes, "gc_cost_units": args.gc_cost_units, "gc_collectors": args.gc_collectors,
+            "gc_slice_cycles": args.gc_slice_cycles, "gc_spec_nodes": args.gc_spec_nodes, "gc_cost_units": args.gc_cost_units or 13, "gc_collectors": args.gc_collectors or 128,
             "checkpoint": checkpoint and os.path.relpath(checkpoint, ROOT),
         },
         "sims_per_sec": n_sims / elapsed,
@@ -379,7 +379,7 @@ def run_agent(args, name, sims, warmup, steps, steady_warmup, steady_steps, ctx,
                  "+ tree kernel + launch gaps) and around every %d-th simulation (measured intervals %.4f / %.4f ms = "
                  "avg_launch_event_ms, each carrying its own event records); avg_launch_ms = the measured intervals scaled by one "
                  "factor to add up to the loop's time per simulation, so avg_launch_ms x %d simulations <= ms_per_step.  The "
-                 "rocprofv3 kernel trace of the same command is profiles/r05_kernel_stats_*.csv"
+                 "rocprofv3 kernel trace of the same command is profiles/r06_kernel_stats_*.csv"
                  % (kf["per_sim_ms"], EV_EVERY, kf["nn_event_ms"], kf["tree_event_ms"], sims))
         nn_roof = {"kernel": (("distributional head (k_dn_conv + k_dn_fc: render, two convolutions, two linear layers and the softmax on the fp32 matrix cores), per launch of %d leaf slots"
                                if args.backend == "hip" else "distributional head (model_distributional.Net on PyTorch-ROCm: MIOpen / rocBLAS kernels + the request render), per evaluation of %d leaves")

@@ -10,7 +10,7 @@
 #   tune     trained net: marking allowance x cost allowance, with the tree kernel's time per launch
 #   bench    the driver's command line
 #   prof     rocprofv3 kernel traces (headline window, both steady-state windows) and the PMC passes of the headline window
-#   lp dist  BASELINE configs[2] / configs[4]: bench line + kernel trace
+#   lp dist  BASELINE configs[2] / configs[4]: bench line + kernel trace + the PMC passes
 #   online   the online self-play run (ValueSimLP, 512 games x 200 sims, fits every 50 moves), MIN minutes (default 11)
 #   evalck   a checkpoint's play strength (same protocol, no training), MIN minutes (default 9), CKPT=<file>
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
@@ -96,9 +96,11 @@ prof)
   prof_kt steady_random 10000 --no-cpu-baseline --steady-steps 0 --others none --warmup 75 --steps 20
   prof_kt steady_trained 10000 --checkpoint $CK --no-cpu-baseline --steady-steps 0 --others none --warmup 75 --steps 20 ;;
 lp)
-  prof_kt lp 10000 --agent ValueSimLP $HEAD; line $OUT/r06.lp.json ;;
+  prof_kt lp 10000 --agent ValueSimLP $HEAD; line $OUT/r06.lp.json
+  prof_pmc lp 10000 --agent ValueSimLP $HEAD ;;
 dist)
-  prof_kt dist 5000 --agent DistValueSim --sims 1000 --warmup 2 --steps 5 $HEAD; line $OUT/r06.dist.json ;;
+  prof_kt dist 5000 --agent DistValueSim --sims 1000 --warmup 2 --steps 5 $HEAD; line $OUT/r06.dist.json
+  prof_pmc dist 5000 --agent DistValueSim --sims 1000 --warmup 2 --steps 5 $HEAD ;;
 ldsprobe)
   # the LDS bank conflicts of k_vn_conv's conv2 reads, MEASURED by removing them: a variant whose reads go to pitch-6 addresses
   # (32 consecutive floats a half-wave: conflict-free; the results are wrong, the instruction stream is the same) against the product,
