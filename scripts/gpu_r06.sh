@@ -11,6 +11,7 @@
 #   bench    the driver's command line
 #   prof     rocprofv3 kernel traces (headline window, both steady-state windows) and the PMC passes of the headline window
 #   lp dist  BASELINE configs[2] / configs[4]: bench line + kernel trace + the PMC passes
+#   timeline one k_sim_step launch dissected (steady state, both nets): start / end of every simulation wave and collector workgroup
 #   online   the online self-play run (ValueSimLP, 512 games x 200 sims, fits every 50 moves), MIN minutes (default 11)
 #   evalck   a checkpoint's play strength (same protocol, no training), MIN minutes (default 9), CKPT=<file>
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
@@ -125,5 +126,12 @@ evalck)
   timeout $((MIN*60+120)) python scripts/selfplay_online.py --minutes $MIN --max-nodes 100000 --games 512 --sims 200 --train-every 250 \
      --load $CKPT --no-train --out $OUT/r06.checkpoint_play.jsonl > $OUT/r06.checkpoint_play.log 2>&1; echo "rc=$?"
   tail -n 1 $OUT/r06.checkpoint_play.log | cut -c1-600 ;;
+timeline)
+  # one launch dissected: when its simulation waves and its collector workgroups start and end (a -DTM_TIMELINE build)
+  bash scripts/build_variant.sh timeline tree.hip '1i #define TM_TIMELINE 1' | tail -n 1
+  TETRIS_MCTS_LIB=$R/build_variants/timeline.so timeout 600 python scripts/launch_timeline.py --out $OUT/r06.launch_timeline_random.json > $OUT/r06.launch_timeline_random.log 2>&1; echo "random rc=$?"
+  TETRIS_MCTS_LIB=$R/build_variants/timeline.so timeout 600 python scripts/launch_timeline.py --checkpoint $CK --out $OUT/r06.launch_timeline_trained.json > $OUT/r06.launch_timeline_trained.log 2>&1; echo "trained rc=$?"
+  TETRIS_MCTS_LIB=$R/build_variants/timeline.so timeout 600 python scripts/launch_timeline.py --checkpoint $CK --warm-moves 10 --moves 4 --out $OUT/r06.launch_timeline_trained_head.json > $OUT/r06.launch_timeline_trained_head.log 2>&1; echo "trained head rc=$?"
+  tail -n 4 $OUT/r06.launch_timeline_random.log | cut -c1-1500; tail -n 4 $OUT/r06.launch_timeline_trained.log | cut -c1-1500; tail -n 2 $OUT/r06.launch_timeline_trained_head.log | cut -c1-1500 ;;
 *) echo "unknown part $p" ;;
 esac; done

@@ -1905,7 +1905,7 @@ struct GcLds {
     int scan[8];                     // Grp<256> scratch
     int n_list;
     int list_g[GC_LIST_MAX], list_ph[GC_LIST_MAX];       // the collecting games and their phase words as of the start of the launch
-    int list_step[GC_LIST_MAX];                         // the launch's plan: the step performed for the game,
+    unsigned char list_step[GC_LIST_MAX];               // the launch's plan: the step performed for the game,
     short list_part[GC_LIST_MAX], list_parts[GC_LIST_MAX], list_share[GC_LIST_MAX];     // this workgroup's share (part of parts; parts 0: not in this launch)
     unsigned char list_mark[GC_LIST_MAX];               // ... and whether this workgroup is the game's marker in this launch
     unsigned char list_mpart[GC_LIST_MAX], list_mparts[GC_LIST_MAX];     // ... with which share of the game's index range (part of parts)
@@ -1925,9 +1925,11 @@ struct GcLds {
     __attribute__((aligned(16))) uint32_t marks[1];     // (the two mark bitmaps of the game under work follow: gc_marks_in_lds)
 };
 static_assert(64 * WPB == 256, "GcLds::hist has one bin per thread of a collector workgroup");
-// k_sim_step's workgroups are five per CU (96 registers a wave): 160 KB / 5.  The marker keeps both bitmaps of the game it
+// k_sim_step's workgroups are five per CU (96 registers a wave), and gfx950 hands out its 160 KB of LDS in granules of 1 280
+// bytes: 25 granules = 32 000 bytes a workgroup (at 32 032 bytes a CU held four - measured, scripts/launch_timeline.py: an
+// eighth of the grid's workgroups started when the first ones had finished).  The marker keeps both bitmaps of the game it
 // marks in LDS when they fit beside GcLds (N <= 100 000: 2 x 12.5 KB); beyond that they stay in memory (same code, atomics).
-constexpr size_t GC_LDS_MAX = 32768 - 256;      // (256 bytes of static LDS come with the kernel: __syncthreads_or's)
+constexpr size_t GC_LDS_GRANULE = 1280, GC_LDS_MAX = (163840 / 5 / GC_LDS_GRANULE) * GC_LDS_GRANULE;
 __host__ __device__ inline bool gc_marks_in_lds(int N) { return offsetof(GcLds, marks) + 2 * gc_bm_bytes(N) <= GC_LDS_MAX; }
 __host__ __device__ inline size_t gc_lds_bytes(int N) { return offsetof(GcLds, marks) + (gc_marks_in_lds(N) ? 2 * gc_bm_bytes(N) : 16); }
 static_assert(offsetof(GcLds, marks) + 2 * 12512 <= GC_LDS_MAX, "the reference's pool (ValueSim.py:16: 100 000 nodes) is marked in LDS");
@@ -2843,7 +2845,20 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_sim_step(tm_store S, int flags)
             S.eval_cnt[(size_t)threadIdx.x * 2 + (S.eval_parity ^ 1)] = 0;
         // (a collector wave shares its SIMD with four simulation waves and is the one a blocked game waits for: it goes first)
         __builtin_amdgcn_s_setprio(3);
+#ifdef TM_TIMELINE   // (measurement builds, scripts/launch_timeline.py: when this workgroup started and ended, 100 MHz ticks)
+        const unsigned tl0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
         gc_collector_block(S, flags, n_gc, *reinterpret_cast<GcLds*>(sim_lds));
+#ifdef TM_TIMELINE
+        if (lane == 0 && (flags & TM_SIM_FRONT) && !(flags & TM_SIM_GC_FULL) && !S.game_list && (int)blockIdx.x + 3 * n_gc < S.n_games) {
+            // collector b: words 34 / 35 of game b's block (odd launches: game 2 n_gc + b's), the launch in word 34 of the
+            // block n_gc further on
+            const size_t row = (size_t)blockIdx.x + ((((unsigned)flags >> 8) & 1) ? 2 * n_gc : 0);
+            if (w == 0) S.gs[row * TM_GS_DW + TM_GS_GC_RSV0] = (int)tl0;
+            if (w == 0) S.gs[(row + n_gc) * TM_GS_DW + TM_GS_GC_RSV0] = (int)((unsigned)flags >> 8);
+            atomicMax(reinterpret_cast<unsigned*>(S.gs + row * TM_GS_DW + TM_GS_GC_RSV1), (unsigned)__builtin_amdgcn_s_memrealtime());
+        }
+#endif
         return;
     }
     // simulation wave i takes game i, or - a launch over some of the games: the catch-up launches - game_list[i]
@@ -2853,6 +2868,9 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_sim_step(tm_store S, int flags)
     GP P = game_ptrs(S, g);
     WaveLds& L = lds[w];
     int32_t* gs = P.gs();
+#ifdef TM_TIMELINE
+    const unsigned tl0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
     // The game's control block (64 words) in one coalesced load: word i in lane i, read with v_readlane.  A word is read
     // from the snapshot only before this launch writes it (the halves below write each word once, from lane 0).
     int gsv = gs[lane];
@@ -2887,13 +2905,23 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_sim_step(tm_store S, int flags)
         __threadfence_block();
     }
     const long long t1 = __builtin_readcyclecounter();
+#ifndef TM_TIMELINE
     if (lane == 0) gs[TM_GS_CYC_BACK] = (int)(t1 - t0);
+#endif
     // the per-move quota (tm_move_begin): games that lost launches to a collection catch up in extra launches
     if ((flags & TM_SIM_FRONT) && GSV(gsv, TM_GS_SIM_STARTED) < GSV(gsv, TM_GS_SIM_TARGET)) {
         if (dist) wave_dist_front<VANILLA>(S, P, L, g, lane, gsv, gc_req_word, flags);
         else wave_sim_front<VANILLA>(S, P, L, VANILLA ? &mt_lds[w] : nullptr, g, lane, gsv, gc_req_word, flags);
     }
     else if (lane < S.eval_slots) P.eval_obs()[lane] = 0;   // nothing started: no request (the evaluator skips empty slots)
+#ifdef TM_TIMELINE
+    if (lane == 0 && (flags & TM_SIM_FRONT) && !(flags & TM_SIM_GC_FULL) && !S.game_list &&
+        GSV(gsv, TM_GS_SIM_STARTED) < GSV(gsv, TM_GS_SIM_TARGET)) {      // (the move's regular launches: all games; a simulation was started)
+        gs[TM_GS_CYC_BACK] = (int)tl0;            // (in place of the phase cycles, which nothing on the device reads)
+        gs[TM_GS_CYC_SELECT] = (int)__builtin_amdgcn_s_memrealtime();
+        gs[TM_GS_CYC_EXPAND] = (int)((unsigned)flags >> 8);
+    }
+#endif
 }
 
 // per-move simulation quota (TreeAgent.play: self.mcts(self.root, self.sims), agents/agent.py:147-150)
