@@ -132,6 +132,9 @@ timeline)
   TETRIS_MCTS_LIB=$R/build_variants/timeline.so timeout 600 python scripts/launch_timeline.py --out $OUT/r06.launch_timeline_random.json > $OUT/r06.launch_timeline_random.log 2>&1; echo "random rc=$?"
   TETRIS_MCTS_LIB=$R/build_variants/timeline.so timeout 600 python scripts/launch_timeline.py --checkpoint $CK --out $OUT/r06.launch_timeline_trained.json > $OUT/r06.launch_timeline_trained.log 2>&1; echo "trained rc=$?"
   TETRIS_MCTS_LIB=$R/build_variants/timeline.so timeout 600 python scripts/launch_timeline.py --checkpoint $CK --warm-moves 10 --moves 4 --out $OUT/r06.launch_timeline_trained_head.json > $OUT/r06.launch_timeline_trained_head.log 2>&1; echo "trained head rc=$?"
+  # the same with the 32 032 bytes of LDS a workgroup had until the fix (26 granules of 1 280: four workgroups a CU)
+  bash scripts/build_variant.sh timeline4 tree.hip '1i #define TM_TIMELINE 1' 's/    return (sim > gc ? sim : gc);/    return 32032;/' | tail -n 1
+  TETRIS_MCTS_LIB=$R/build_variants/timeline4.so timeout 600 python scripts/launch_timeline.py --checkpoint $CK --moves 3 --out $OUT/r06.launch_timeline_trained_4_per_cu.json > $OUT/r06.launch_timeline_trained_4_per_cu.log 2>&1; echo "trained, 4 per CU rc=$?"
   tail -n 4 $OUT/r06.launch_timeline_random.log | cut -c1-1500; tail -n 4 $OUT/r06.launch_timeline_trained.log | cut -c1-1500; tail -n 2 $OUT/r06.launch_timeline_trained_head.log | cut -c1-1500 ;;
 *) echo "unknown part $p" ;;
 esac; done
