@@ -51,6 +51,10 @@ for m in range(a.moves):
         print("   game %4d lag %3d collections %d stalled launches %3d speculative launches %3d free nodes %5d reachable at last gc %5d phase %2d pool_full %d slices %d"
               % (g, lag[g], ngc[g], stall[g], spec[g], g1[g, 2], g1[g, 24], g1[g, 32] & 15, g1[g, 44], g1[g, 38] - g0[g, 38]))
         print("        launches by phase [req, mark, count, write, nodes, obs, done | spec-req, spec-mark, req-spec, -, req-over]:", hist[g, 1:8].tolist(), hist[g, 8:13].tolist())
+        ml = max(1, g1[g, 37] - g0[g, 37])
+        print("        marker: launches %d, workgroups per launch %.2f, games its workgroups had %.2f, blocks %d, rounds %d, kcycles of its workgroups per launch %.0f, wave kcycles per block %.1f, idle turns %d"
+              % (g1[g, 37] - g0[g, 37], (g1[g, 58] - g0[g, 58]) / ml, (g1[g, 59] - g0[g, 59]) / ml, g1[g, 51] - g0[g, 51], g1[g, 52] - g0[g, 52],
+                 (g1[g, 53] - g0[g, 53]) * 64 / 1e3 / ml, (g1[g, 62] - g0[g, 62]) * 64 / 1e3 / max(1, g1[g, 51] - g0[g, 51]), g1[g, 63] - g0[g, 63]))
     col = ngc >= 1
     if col.any():
         names = ["req", "mark", "count", "write", "nodes", "obs", "done", "spec-req", "spec-mark", "req-spec", "-", "req-over"]
