@@ -11,6 +11,7 @@
 #   bench    the driver's command line
 #   prof     rocprofv3 kernel traces (headline window, both steady-state windows) and the PMC passes of the headline window
 #   lp dist  BASELINE configs[2] / configs[4]: bench line + kernel trace + the PMC passes
+#   vn       the gate of a value-net change: parity tests, kernel traces of the headline window and of ValueSimLP
 #   timeline one k_sim_step launch dissected (steady state, both nets): start / end of every simulation wave and collector workgroup
 #   online   the online self-play run (ValueSimLP, 512 games x 200 sims, fits every 50 moves), MIN minutes (default 11)
 #   evalck   a checkpoint's play strength (same protocol, no training), MIN minutes (default 9), CKPT=<file>
@@ -126,6 +127,11 @@ evalck)
   timeout $((MIN*60+120)) python scripts/selfplay_online.py --minutes $MIN --max-nodes 100000 --games 512 --sims 200 --train-every 250 \
      --load $CKPT --no-train --out $OUT/r06.checkpoint_play.jsonl > $OUT/r06.checkpoint_play.log 2>&1; echo "rc=$?"
   tail -n 1 $OUT/r06.checkpoint_play.log | cut -c1-600 ;;
+vn)
+  # the gate of a value-net change: its parity tests, then the headline window's and ValueSimLP's kernel traces
+  timeout 600 python -m pytest -x -q -m gpu tests/test_gpu_valuenet.py > $OUT/r06.vn_tests.log 2>&1; tail -n 2 $OUT/r06.vn_tests.log
+  prof_kt head 10000 $HEAD; line $OUT/r06.head.json
+  prof_kt lp 10000 --agent ValueSimLP $HEAD; line $OUT/r06.lp.json ;;
 timeline)
   # one launch dissected: when its simulation waves and its collector workgroups start and end (a -DTM_TIMELINE build)
   bash scripts/build_variant.sh timeline tree.hip '1i #define TM_TIMELINE 1' | tail -n 1

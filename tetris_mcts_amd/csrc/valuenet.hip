@@ -246,7 +246,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // anybody.  `cnt`: one int per tile (the first pad word of the scratch row of the tile's first state), zeroed by k_vn_conv at
 // the start of every evaluation (the kernel also leaves it zero).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int RT, int NY, int KC, int WRING>
+#ifdef TM_FC1_TIMELINE   // (measurement builds, scripts/fc1_timeline.py: thread 0's s_memrealtime at the kernel's stations, in the pad words of
+                         //  scratch row s0 + blockIdx.y)
+#define FC1_STAMP(i) do { if (threadIdx.x == 0 && s0 + (int)blockIdx.y < n) reinterpret_cast<int*>(hout)[(size_t)(s0 + blockIdx.y) * hstride + HID + 1 + (i)] = (int)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FC1_STAMP(i) do { } while (0)
+#endif
+template <int RT, int NY, int KC, int WRING, int PF>
 __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, const float* __restrict__ prep,
                                                 const float* __restrict__ a3, int a3stride, int n,
                                                 float* __restrict__ hout, int hstride,
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, l15 = lane & 15;
     const int s0 = blockIdx.x * ROWS;
     int my_slot = 0;
+    FC1_STAMP(0);
     if (rq.list) {
         // rows = dense positions of the request list; a tile past its end has nothing to do (all of its workgroups leave,
         // before they have asked the memory system for anything else)
@@ -285,27 +292,6 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     for (int t = 0; t < NST; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = P[OFF_F1B + 16 * ht + kk * 4 + r];
-    // staging: ROWS rows x KC floats per chunk, KC/4 threads per row, 16-byte pieces
-    constexpr int TPR = KC / 4, RPP = 512 / TPR, NPASS = ROWS / RPP;
-    const int row0 = threadIdx.x / TPR, c4 = (threadIdx.x % TPR) * 4;
-    // The activations of chunk c + 2 are requested while chunk c is multiplied (two register sets): a tile's rows were written
-    // by convolution waves all over the chip, so they come from beyond this XCD's L2, and one chunk of MFMAs (under 2 us) does
-    // not cover that round trip.  (Kept as a select: a plain 16-byte copy into the array sent the whole array to scratch
-    // memory - tests/test_abi.py holds every hot kernel to a private segment of 0.)
-    float4 st[2][NPASS];
-    auto gload = [&](int chunk) {
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int sa = s0 + row0 + RPP * i;
-            st[chunk & 1][i] = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * KC + c4)
-                                        : make_float4(0, 0, 0, 0);
-        }
-    };
-    auto lstore = [&](int chunk) {
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i)
-            *reinterpret_cast<float4*>(&bt[chunk & 1][(row0 + RPP * i) * PITCH + c4]) = st[chunk & 1][i];
-    };
     constexpr int NCH = A3 / KC;          // chunks of KC k = KC/4 MFMA steps
     // a group = GRP MFMA steps (per state tile) = GRP/4 weight quads; weights: a ring of WRING groups, the group WRING - 1 ahead
     // requested while a group is multiplied (measured, r04 calls C-E per launch of ~60 32-state tiles: chunk-deep weights without
@@ -318,14 +304,46 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
 #pragma unroll
         for (int q = 0; q < QPG; ++q) wring[G % WRING][q] = W[((size_t)G * QPG + q) * 64];
     };
-    gload(0);
-    gload(1);
+    // The first weights (and the biases above) are requested BEFORE the activations: a wave's loads return in order, and the first
+    // MFMA needs both.  (Requested before the request list's counters are read, by every workgroup of the grid: 34.4 us against 31.5.)
 #pragma unroll
     for (int G0 = 0; G0 < WRING - 1; ++G0) wload(G0);
+    // staging: ROWS rows x KC floats per chunk, KC/4 threads per row, 16-byte pieces
+    constexpr int TPR = KC / 4, RPP = 512 / TPR, NPASS = ROWS / RPP;
+    const int row0 = threadIdx.x / TPR, c4 = (threadIdx.x % TPR) * 4;
+    // The activations of chunk c + 2 are requested while chunk c is multiplied (two register sets): a tile's rows were written
+    // by convolution waves all over the chip, so they come from beyond this XCD's L2, and one chunk of MFMAs (under 2 us) does
+    // not cover that round trip.  (Kept as a select: a plain 16-byte copy into the array sent the whole array to scratch
+    // memory - tests/test_abi.py holds every hot kernel to a private segment of 0.)
+    // r06 (scripts/fc1_timeline.py, the kernel's stations in time): PF register sets = PF chunks in flight, the request for chunk
+    // c + PF issued at the START of chunk c's MFMAs (until then it went out after them: one chunk of cover, not two), and the
+    // first weights requested before the first activations (a wave's loads return in order).  1 867 states, entry to outputs:
+    // 34.2 us before; PF = 2 / 3 / 4 / 7 (the whole tile up front): 28.9 / 29.6 / 30.2 / 32.6 - the more is asked for at once, the
+    // later the first chunk is there (4.5 ... 9.4 us), and the K loop does not shorten (18 - 19 us for 12 of matrix time).
+    float4 st[PF][NPASS];
+    auto gload = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int sa = s0 + row0 + RPP * i;
+            st[chunk % PF][i] = (sa < n) ? *reinterpret_cast<const float4*>(a3 + (size_t)sa * a3stride + chunk * KC + c4)
+                                         : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i)
+            *reinterpret_cast<float4*>(&bt[chunk & 1][(row0 + RPP * i) * PITCH + c4]) = st[chunk % PF][i];
+    };
+    static_assert(PF >= 2 && PF <= A3 / KC, "chunks in flight");
+#pragma unroll
+    for (int c = 0; c < PF; ++c) gload(c);
+    FC1_STAMP(1);
     lstore(0);
     __syncthreads();
+    FC1_STAMP(2);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+        if (c + PF < NCH) gload(c + PF);         // into the register set chunk c's staging has left (lstore(c): before the last barrier)
         const float* b0 = &bt[c & 1][(16 * st0 + l15) * PITCH + kk];
         // The B operands (LDS) of the next group of MFMA steps are requested while this group's MFMAs issue (r03 - r04 call C:
         // the compiler's own order was read, wait for it, two MFMAs, read ...: an LDS round trip per pair of MFMAs, 45 us per
@@ -360,9 +378,9 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
             }
             __builtin_amdgcn_sched_barrier(0);      // the next group's reads stay in this group's region: a whole group ahead of their use
         }
-        if (c + 1 < NCH) lstore(c + 1);          // (requested a whole chunk ago)
-        if (c + 2 < NCH) gload(c + 2);           // into the register set chunk c's staging has just left
+        if (c + 1 < NCH) lstore(c + 1);          // (requested PF - 1 chunks ago)
         __syncthreads();
+        if (c == NCH - 1) FC1_STAMP(3);
     }
     // D[i = kk*4 + r][j = l15]: four consecutive hidden units of one state per lane -> one 16-byte write-through store,
     // and a copy into LDS (hs[state][hidden unit], the layout the output layer below reads)
@@ -384,6 +402,7 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
     if (rq.list && w == 0 && lane < ROWS) row_slot[lane] = my_slot;      // (the list entry has had the whole K loop to arrive)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    FC1_STAMP(4);
     if (threadIdx.x == 0) {
         // (relaxed on purpose: the hand-off is carried by the write-through sc1 stores + s_waitcnt before the arrival and the sc1
         // loads after it - MI355X_MICROARCH.md's measured form.  With __ATOMIC_ACQ_REL here the compiler adds buffer_wbl2 sc1 /
@@ -394,6 +413,7 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
         if (old == NY - 1) __hip_atomic_store(&cnt[(size_t)blockIdx.x * cnt_stride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
     }
     __syncthreads();
+    FC1_STAMP(5);
     if (last_flag != NY - 1) return;
     // ---- this workgroup arrived last: the other parts of h past the caches (ROWS states x (256 - UNITS) units) ----
     {
@@ -419,6 +439,7 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
         }
     }
     __syncthreads();
+    FC1_STAMP(6);
     if (threadIdx.x < 2 * ROWS) {
         // one chain per lane: state j = t >> 1, output o = t & 1 (k_fc_out's thread t = 2 s + o); fma over the 256 hidden units
         // in order
@@ -430,8 +451,20 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
             float a = P[OFF_FOB + o];
             const float* x = &hs[j * HS_PITCH];
             const float* wr = P + OFF_FOW + o * HID;
+            // the same chain in the same order, its operands fetched four at a time (r06, scripts/fc1_timeline.py: this loop was
+            // 4.5 us of the tile's last workgroup - a scalar LDS read and a scalar global read in front of every fma)
+            if ((reinterpret_cast<uintptr_t>(wr) & 15) == 0) {
+                const float4* x4 = reinterpret_cast<const float4*>(x);
+                const float4* w4 = reinterpret_cast<const float4*>(wr);
 #pragma unroll 8
-            for (int i = 0; i < HID; ++i) a = fmaf(x[i], wr[i], a);
+                for (int i = 0; i < HID / 4; ++i) {
+                    const float4 xv = x4[i], wv = w4[i];
+                    a = fmaf(xv.x, wv.x, a); a = fmaf(xv.y, wv.y, a); a = fmaf(xv.z, wv.z, a); a = fmaf(xv.w, wv.w, a);
+                }
+            } else {
+#pragma unroll 8
+                for (int i = 0; i < HID; ++i) a = fmaf(x[i], wr[i], a);
+            }
             const double e = tm_exp(-(double)a);
             const float sg = (float)(1.0 / (1.0 + e));
             const float tt = sg * P[OFF_UB + o];
@@ -439,6 +472,7 @@ __global__ __launch_bounds__(512) void k_vn_fc1(const float* __restrict__ P, con
             if (o == 0) v_out[sidx] = res; else var_out[sidx] = res;
         }
     }
+    FC1_STAMP(7);
 }
 
 }  // namespace tmcts_vn
@@ -492,10 +526,10 @@ static int vn_forward_impl(const float* P, const float* prepared, const int8_t* 
     hipLaunchKernelGGL(k_vn_conv, dim3(blocks), dim3(256), lds, stream, P, prepared, states, obs_key, rq,
                        max_nodes, n, scratch, SS, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS);
     if (n >= 8192)      // (request slots: the leaf-parallel kinds' seven per game)
-        hipLaunchKernelGGL((k_vn_fc1<4, 4, 128, 3>), dim3((n + 63) / 64, 4), dim3(512), 0, stream, P, prepared, scratch, SS, n,
+        hipLaunchKernelGGL((k_vn_fc1<4, 4, 128, 3, 2>), dim3((n + 63) / 64, 4), dim3(512), 0, stream, P, prepared, scratch, SS, n,
                            scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 64 * SS, v, var);
     else
-        hipLaunchKernelGGL((k_vn_fc1<2, 4, 256, 6>), dim3((n + 31) / 32, 4), dim3(512), 0, stream, P, prepared, scratch, SS, n,
+        hipLaunchKernelGGL((k_vn_fc1<2, 4, 256, 6, 2>), dim3((n + 31) / 32, 4), dim3(512), 0, stream, P, prepared, scratch, SS, n,
                            scratch + A3, SS, rq, reinterpret_cast<int32_t*>(scratch + A3 + HID), 32 * SS, v, var);
     return (int)hipGetLastError();
 }
