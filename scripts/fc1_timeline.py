@@ -34,6 +34,12 @@ for it in range(6):
            "epilogue_last_us": pc(us[last, 7] - us[last, 5]) if last.any() else None}
     row["entry_deciles_us"] = [round(float(np.percentile(us[:, 0], q)), 1) for q in range(0, 101, 10)]
     row["entry_by_y_mean_us"] = [round(float(us[y::4, 0].mean()), 1) for y in range(4)]
+    cs = sc[:, 2057:2063].astype(np.uint32).astype(np.int64)        # the convolution's waves (one state each at these sizes): entry,
+    cu = (cs - cs[:, 0].min()) / 100.0                                #  loop entered, input rendered, conv1, conv2, conv3 + stored
+    row["conv"] = {"states": int(B), "entry": pc(cu[:, 0]), "constants_and_request_resolved": pc(cu[:, 1]), "input_rendered": pc(cu[:, 2]),
+                   "conv1_done": pc(cu[:, 3]), "conv2_done": pc(cu[:, 4]), "conv3_stored": pc(cu[:, 5]),
+                   "per_wave_us": {"prologue": pc(cu[:, 1] - cu[:, 0]), "render": pc(cu[:, 2] - cu[:, 1]), "conv1": pc(cu[:, 3] - cu[:, 2]),
+                                   "conv2": pc(cu[:, 4] - cu[:, 3]), "conv3": pc(cu[:, 5] - cu[:, 4])}}
     if it >= 2:
         rows.append(row)
         print(json.dumps(row), flush=True)
