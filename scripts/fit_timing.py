@@ -11,6 +11,9 @@ values = (states.sum(dim=(1, 2, 3)) * 0.5 + 20).reshape(-1, 1)
 variances = torch.full((n, 1), 4.0, device="cuda")
 weights = torch.from_numpy(rng.integers(10, 200, size=(n, 1)).astype(np.float32)).cuda()
 os.chdir("/tmp")
+if os.environ.get("TM_FIT_BENCHMARK") == "1":      # MIOpen's search for the convolutions' kernels instead of its default pick
+    torch.backends.cudnn.benchmark = True
+print("cudnn.benchmark (MIOpen find)", torch.backends.cudnn.benchmark, flush=True)
 for mode in ("0", "1"):
     os.environ["TM_TRAIN_GRAPH"] = mode
     mdl = M.Model_VV(backend="torch", seed=0)
