@@ -68,7 +68,12 @@ enum {
                             launch); speculative marking while the game simulates: (launch << 4) | 8 requested, 9 under way,
                             (launch << 4) | 10 the pool ran dry meanwhile */
     TM_GS_GC_ARRIVE,     /* collector workgroups that have done their share of the current step (bits 8..: some left work) */
-    TM_GS_GC_RSV0, TM_GS_GC_RSV1, /* (unused) */
+    TM_GS_GC_ACTIVE4,    /* in the control block of every FOURTH game (game 4k of the store or slice - slices begin at multiples of four
+                            games): bit j = game 4k + j's phase word may be non-zero.  The collector workgroups of a launch look at
+                            these words and read the phase words they point at, instead of every game's (set with the request by the
+                            game's wave, cleared by it when it resumes; a bit without a phase is harmless, a phase without its bit
+                            would never be served) */
+    TM_GS_GC_RSV1,       /* (unused) */
     TM_GS_GC_WORK,       /* marking: chunks were flagged when the last launch that looked ended (the next one marks) */
     TM_GS_GC_MARK_LAUNCHES, /* launches in which a collector workgroup marked for this game (all collections) */
     TM_GS_GC_SLICES,     /* launches in which collector workgroups worked on a collection of this game (all collections) */
@@ -271,7 +276,8 @@ int tm_sim_step(const tm_store *s, int flags, void *stream);
 int tm_eval_render(const tm_store *s, int8_t *out /* [G*eval_slots][200] */, void *stream);
 
 /* The store of games [first, first+n) of *s (every array is per game contiguous: a slice is the same struct with
- * offset pointers).  Sub-batches of one process, shards of a multi-GPU job. */
+ * offset pointers).  Sub-batches of one process, shards of a multi-GPU job.  `first` is a multiple of four (a tree-kernel
+ * workgroup's games; the groups of TM_GS_GC_ACTIVE4): hipErrorInvalidValue otherwise. */
 int tm_store_slice(const tm_store *s, int first, int n, tm_store *out);
 
 /* Native driver of one move's search = the reference's `for i in range(sims)` loop (agents/ValueSim.py:76-94,

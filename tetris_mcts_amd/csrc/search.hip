@@ -50,7 +50,8 @@ struct tm_search {
 extern "C" {
 
 int tm_store_slice(const tm_store* s, int first, int n, tm_store* out) {
-    if (first < 0 || n < 0 || first + n > s->n_games) return (int)hipErrorInvalidValue;
+    // (a slice begins at a multiple of four games: a tree-kernel workgroup's games, and the groups of TM_GS_GC_ACTIVE4)
+    if (first < 0 || (first & 3) || n < 0 || first + n > s->n_games) return (int)hipErrorInvalidValue;
     tm_store t = *s;
     const size_t f = (size_t)first, N = (size_t)s->max_nodes;
     const size_t bm_bytes = ((N + 7) / 8 + 15) & ~(size_t)15;

@@ -82,6 +82,12 @@ struct GP {
     __device__ __forceinline__ float* eval_var() const { return S.eval_var + (size_t)g * S.eval_slots; }
     __device__ __forceinline__ uint32_t* trace() const { return S.trace + (size_t)g * (size_t)S.max_trace * 4; }
 };
+// The summary of the phase words (TM_GS_GC_ACTIVE4: a bit a game in the control block of every fourth game): what lets a
+// launch's collector workgroups find the collecting games without reading every game's control block - 4 096 scattered lines a
+// workgroup, 128 workgroups, every launch: 1.7 us of every k_sim_step launch, measured by leaving the look out (r06).  Set by
+// whoever makes a phase word non-zero, cleared by whoever owns the game when the word goes back to zero.
+__device__ __forceinline__ void gc_active_set(const GP& P) { atomicOr(&P.S.gs[(size_t)(P.g & ~3) * TM_GS_DW + TM_GS_GC_ACTIVE4], 1 << (P.g & 3)); }
+__device__ __forceinline__ void gc_active_clear(const GP& P) { atomicAnd(&P.S.gs[(size_t)(P.g & ~3) * TM_GS_DW + TM_GS_GC_ACTIVE4], ~(1 << (P.g & 3))); }
 
 __device__ __forceinline__ GP game_ptrs(const tm_store& S, int g) { return GP{S, g}; }
 
@@ -537,6 +543,7 @@ __device__ __forceinline__ bool wave_expand(const tm_store& S, const GP& P, Wave
                     if (lane == 0) {
                         P.gs()[TM_GS_GC_REQ_AT] = gc_req_word >> 4;
                         atomicExch(&P.gs()[TM_GS_GC_PHASE], gc_req_word);
+                        gc_active_set(P);
                         P.gs()[TM_GS_GC_RETRY] = 1;
                     }
                     wave_sync();
@@ -918,7 +925,7 @@ __device__ __forceinline__ void wave_front_finish(const tm_store& S, const GP& P
         // ... and only if the pool can run dry in THIS move (seven nodes a simulation at most): update_root drops the marks
         if (S.gc_spec_nodes > 0 && GSV(gsv, TM_GS_GC_PHASE) == 0 && !leaf_end && !GSV(gsv, TM_GS_POOL_FULL) && !gs[TM_GS_POOL_FULL]) {
             const int nf = gs[TM_GS_NFREE_NODE], sims_left = GSV(gsv, TM_GS_SIM_TARGET) - GSV(gsv, TM_GS_SIM_STARTED);
-            if (nf < S.gc_spec_nodes && nf < 7 * sims_left) gs[TM_GS_GC_PHASE] = (gc_req_word & ~15) | GC_SPEC_REQ;
+            if (nf < S.gc_spec_nodes && nf < 7 * sims_left) { gs[TM_GS_GC_PHASE] = (gc_req_word & ~15) | GC_SPEC_REQ; gc_active_set(P); }
         }
     }
 }
@@ -1856,6 +1863,7 @@ __device__ __forceinline__ void gc_collect(const tm_store& S, const GP& P, int g
         gs[TM_GS_CYC_TAIL] = (int)(((long long)__builtin_readcyclecounter() - gc_t0) >> 4);   // last GC, units of 16 cycles
         gs[TM_GS_CYC_TAIL + 1] = tail;                                                // reachable nodes at the last GC
         gs[TM_GS_GC_PHASE] = 0;
+        gc_active_clear(P);
         gs[TM_GS_GC_SLICES] += 1;
     }
     G_::sync();
@@ -1866,12 +1874,12 @@ __device__ __forceinline__ void gc_collect(const tm_store& S, const GP& P, int g
 __device__ __forceinline__ void gc_drop_speculative(const GP& P, int lane) {
     const int ph = P.gs()[TM_GS_GC_PHASE] & 15;
     wave_sync();
-    if (lane == 0 && (ph == GC_SPEC_REQ || ph == GC_SPEC_MARK)) P.gs()[TM_GS_GC_PHASE] = 0;
+    if (lane == 0 && (ph == GC_SPEC_REQ || ph == GC_SPEC_MARK)) { P.gs()[TM_GS_GC_PHASE] = 0; gc_active_clear(P); }
     if (lane == 0) P.gs()[TM_GS_GC_IN_MOVE] = 0;      // (and what a collection left behind no longer says what is reachable)
     wave_sync();
 }
 __device__ __forceinline__ void gc_wave(const tm_store& S, const GP& P, int g, int lane) {
-    if (lane == 0) P.gs()[TM_GS_GC_PHASE] = GC_REQ;
+    if (lane == 0) { P.gs()[TM_GS_GC_PHASE] = GC_REQ; gc_active_set(P); }
     __threadfence_block();
     gc_collect<64>(S, P, g, lane, nullptr);
 }
@@ -2299,14 +2307,23 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         }
         return -1;
     };
+    // a thread's run of RUN games: the summary words of its four groups of four (TM_GS_GC_ACTIVE4), then the phase words of the
+    // games they point at (in flight together); everybody else's reads as zero
+    static_assert(RUN == 16, "a run = four groups of four games");
+    auto load_run = [&](int base, int (&word)[RUN]) {
+        const int g0 = base + tid * RUN;
+        uint32_t act = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (g0 + 4 * q < S.n_games) act |= ((uint32_t)S.gs[(size_t)(g0 + 4 * q) * TM_GS_DW + TM_GS_GC_ACTIVE4] & 15u) << (4 * q);
+#pragma unroll
+        for (int r = 0; r < RUN; ++r)
+            word[r] = ((act >> r) & 1u) && g0 + r < S.n_games ? S.gs[(size_t)(g0 + r) * TM_GS_DW + TM_GS_GC_PHASE] : 0;
+    };
     int n_wait_all = 0;
     for (int base = 0; base < S.n_games; base += T * RUN) {
         int word[RUN];
-#pragma unroll
-        for (int r = 0; r < RUN; ++r) {
-            const int g = base + tid * RUN + r;
-            word[r] = g < S.n_games ? S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_PHASE] : 0;
-        }
+        load_run(base, word);
         uint32_t todo_w = 0, todo_s = 0;
 #pragma unroll
         for (int r = 0; r < RUN; ++r) {
@@ -2341,11 +2358,12 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         __syncthreads();
         auto age_of = [&](int g) { return min(255, (seq - S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_REQ_AT]) & 0x7FFFF); };
         for (int base = 0; base < S.n_games; base += T * RUN) {
+            int word[RUN];
+            load_run(base, word);
 #pragma unroll
             for (int r = 0; r < RUN; ++r) {
                 const int g = base + tid * RUN + r;
-                int word = g < S.n_games ? S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_PHASE] : 0;
-                if (classify(word) == 0) atomicAdd(&M.hist[age_of(g)], 1);
+                if (classify(word[r]) == 0) atomicAdd(&M.hist[age_of(g)], 1);
             }
         }
         __syncthreads();
@@ -2355,11 +2373,11 @@ __device__ __forceinline__ void gc_collector_block(const tm_store& S, int flags,
         int n_old = 0, n_eq = 0;
         for (int base = 0; base < S.n_games; base += T * RUN) {
             int word[RUN];
+            load_run(base, word);
             uint32_t m_old = 0, m_eq = 0;
 #pragma unroll
             for (int r = 0; r < RUN; ++r) {
                 const int g = base + tid * RUN + r;
-                word[r] = g < S.n_games ? S.gs[(size_t)g * TM_GS_DW + TM_GS_GC_PHASE] : 0;
                 if (classify(word[r]) == 0) {
                     const int a = age_of(g);
                     if (a > cut) m_old |= 1u << r;
@@ -2850,13 +2868,13 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_sim_step(tm_store S, int flags)
 #endif
         gc_collector_block(S, flags, n_gc, *reinterpret_cast<GcLds*>(sim_lds));
 #ifdef TM_TIMELINE
-        if (lane == 0 && (flags & TM_SIM_FRONT) && !(flags & TM_SIM_GC_FULL) && !S.game_list && (int)blockIdx.x + 3 * n_gc < S.n_games) {
-            // collector b: words 34 / 35 of game b's block (odd launches: game 2 n_gc + b's), the launch in word 34 of the
-            // block n_gc further on
-            const size_t row = (size_t)blockIdx.x + ((((unsigned)flags >> 8) & 1) ? 2 * n_gc : 0);
-            if (w == 0) S.gs[row * TM_GS_DW + TM_GS_GC_RSV0] = (int)tl0;
-            if (w == 0) S.gs[(row + n_gc) * TM_GS_DW + TM_GS_GC_RSV0] = (int)((unsigned)flags >> 8);
-            atomicMax(reinterpret_cast<unsigned*>(S.gs + row * TM_GS_DW + TM_GS_GC_RSV1), (unsigned)__builtin_amdgcn_s_memrealtime());
+        if (lane == 0 && (flags & TM_SIM_FRONT) && !(flags & TM_SIM_GC_FULL) && !S.game_list && (int)blockIdx.x + 6 * n_gc < S.n_games) {
+            // collector b: the spare word 35 of game b's block (start), of game n_gc + b's (end), of game 2 n_gc + b's (the
+            // launch); odd launches 3 n_gc further on
+            const size_t row = (size_t)blockIdx.x + ((((unsigned)flags >> 8) & 1) ? 3 * n_gc : 0);
+            if (w == 0) S.gs[row * TM_GS_DW + TM_GS_GC_RSV1] = (int)tl0;
+            if (w == 0) S.gs[(row + 2 * n_gc) * TM_GS_DW + TM_GS_GC_RSV1] = (int)((unsigned)flags >> 8);
+            atomicMax(reinterpret_cast<unsigned*>(S.gs + (row + n_gc) * TM_GS_DW + TM_GS_GC_RSV1), (unsigned)__builtin_amdgcn_s_memrealtime());
         }
 #endif
         return;
@@ -2884,7 +2902,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_sim_step(tm_store S, int flags)
         else if (gph == GC_SPEC_REQ) gc_req_word = (gc_req_word & ~15) | GC_REQ_OVER;
         else if (gcw != 0) {
             if (gph != GC_DONE || (gcw >> 4) == (int)((unsigned)flags >> 8)) return;
-            if (lane == 0) gs[TM_GS_GC_PHASE] = 0;
+            if (lane == 0) { gs[TM_GS_GC_PHASE] = 0; gc_active_clear(P); }
             gsv = lane == TM_GS_GC_PHASE ? 0 : gsv;       // (the snapshot's phase word is what the finish stage tests)
         }
     }
@@ -3045,7 +3063,7 @@ __global__ __launch_bounds__(64 * WPB) void k_tree_gc(tm_store S, const uint8_t*
     const int g = blockIdx.x;
     if (mask && !mask[g]) return;
     GP P = game_ptrs(S, g);
-    if (threadIdx.x == 0) { P.gs()[TM_GS_GC_PHASE] = GC_REQ; P.gs()[TM_GS_GC_IN_MOVE] = 0; }      // (a speculative marking is simply overwritten)
+    if (threadIdx.x == 0) { P.gs()[TM_GS_GC_PHASE] = GC_REQ; gc_active_set(P); P.gs()[TM_GS_GC_IN_MOVE] = 0; }      // (a speculative marking is simply overwritten)
     __syncthreads();
     gc_collect<64 * WPB>(S, P, g, (int)threadIdx.x, sm);
 }
@@ -3153,6 +3171,7 @@ __global__ void k_pool_reset(tm_store S, const uint8_t* mask) {
         P.gs()[TM_GS_TRACE_LEN] = 0;
         P.gs()[TM_GS_PENDING] = 0;
         P.gs()[TM_GS_GC_PHASE] = 0;
+        gc_active_clear(P);
         P.gs()[TM_GS_GC_RETRY] = 0;
         P.gs()[TM_GS_POOL_FULL] = 0;
         P.gs()[TM_GS_GC_IN_MOVE] = 0;

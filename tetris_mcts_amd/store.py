@@ -14,7 +14,7 @@ SIM_BACKUP, SIM_FRONT, SIM_GC_FULL, SIM_EVAL_NEEDED = 1, 2, 4, 8
 KIND_VALUESIM, KIND_VALUESIM_LP, KIND_CPPAGENT_LP, KIND_CPPAGENT, KIND_VANILLA, KIND_VANILLA_C, KIND_DIST = 0, 1, 2, 3, 4, 5, 6
 GS = dict(ROOT=0, EPISODE=1, NFREE_NODE=2, NFREE_OBS=3, TRACE_LEN=4, PENDING=5, ERR=6, N_EXPAND=7, N_SIMS=8, N_GC=9,
           RNG_POS=10, N_NQ_FALLBACK=11, LEAF=12, LEAF_END=13, K_EVAL=14, LEAF_SCORE=15, TRACE_SUM=16, N_EVAL=17, N_POOL_RESET=18, MAX_TRACE=19, N_DROPPED=25,
-          CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_WORK=36, GC_MARK_LAUNCHES=37, GC_SLICES=38,
+          CYC_BACK=20, CYC_SELECT=21, CYC_EXPAND=22, CYC_GC16=23, GC_REACHABLE=24, GC_PHASE=32, GC_ACTIVE4=34, GC_WORK=36, GC_MARK_LAUNCHES=37, GC_SLICES=38,
           SIM_TARGET=40, SIM_STARTED=41, CYC_VERIFY=42, FIRST_MISS=28, PREFIX_SUM=29, N_WALK_MISS=43, POOL_FULL=44, GC_IN_MOVE=45, GC_REQ_AT=46,
           LEAF_OBS=47, N_EVAL_SKIP=48, N_EVAL_CACHED=49, GC_NGC=50, GC_BLOCKS=51, GC_ITERS=52, GC_MARK_CYC=53, GC_FLAGS=54, GC_MARK_PARTS=58, GC_MARK_SHARED=59, GC_CYC_LOAD=60, GC_CYC_ROUNDS=61, GC_CYC_WAVES=62, GC_IDLE_TURNS=63)
 
