@@ -12,6 +12,7 @@
 #   prof     rocprofv3 kernel traces (headline window, both steady-state windows) and the PMC passes of the headline window
 #   lp dist  BASELINE configs[2] / configs[4]: bench line + kernel trace + the PMC passes
 #   vn       the gate of a value-net change: parity tests, kernel traces of the headline window and of ValueSimLP
+#   stations the value net's kernels in time (fc1's workgroups, the convolution's waves): profiles/r06_valuenet_stations_*.json
 #   timeline one k_sim_step launch dissected (steady state, both nets): start / end of every simulation wave and collector workgroup
 #   online   the online self-play run (ValueSimLP, 512 games x 200 sims, fits every 50 moves), MIN minutes (default 11)
 #   evalck   a checkpoint's play strength (same protocol, no training), MIN minutes (default 9), CKPT=<file>
@@ -132,6 +133,12 @@ vn)
   timeout 600 python -m pytest -x -q -m gpu tests/test_gpu_valuenet.py > $OUT/r06.vn_tests.log 2>&1; tail -n 2 $OUT/r06.vn_tests.log
   prof_kt head 10000 $HEAD; line $OUT/r06.head.json
   prof_kt lp 10000 --agent ValueSimLP $HEAD; line $OUT/r06.lp.json ;;
+stations)
+  # the value net's kernels in time: every k_vn_fc1 workgroup's and every k_vn_conv wave's stations (a -DTM_FC1_TIMELINE build)
+  bash scripts/build_variant.sh fc1tl valuenet.hip '1i #define TM_FC1_TIMELINE 1' | tail -n 1
+  for B in 1867 8960; do
+    TETRIS_MCTS_LIB=$R/build_variants/fc1tl.so timeout 300 python scripts/fc1_timeline.py $B $OUT/r06.fc1_timeline_$B.json 2>&1 | tail -n 1 | cut -c1-600
+  done ;;
 timeline)
   # one launch dissected: when its simulation waves and its collector workgroups start and end (a -DTM_TIMELINE build)
   bash scripts/build_variant.sh timeline tree.hip '1i #define TM_TIMELINE 1' | tail -n 1
