@@ -239,3 +239,21 @@ def test_dense_request_list_addressing():
             at = (sg + segs * (d // slots)) * slots + d % slots
             seen.add(lst[at])
         assert len(seen) == total
+
+
+def test_a_slice_begins_at_a_multiple_of_four_games():
+    """tm_store_slice (host arithmetic only: callable without a GPU): games [first, first + n) as a store of their own - `first` a
+    multiple of four (a tree-kernel workgroup's games; the groups of the collectors' summary words, TM_GS_GC_ACTIVE4), anything
+    else is refused; every per-game array advances by first x its per-game size."""
+    L = _lib()
+    lib = L.lib()
+    s, out = L.TmStore(), L.TmStore()
+    s.n_games, s.max_nodes, s.table_cap, s.eval_slots, s.max_trace, s.replay_cap = 64, 1000, 2048, 7, 256, 0
+    for first, n, rc_ok in ((0, 64, True), (4, 60, True), (32, 8, True), (2, 8, False), (5, 4, False), (60, 8, False), (-4, 4, False)):
+        rc = lib.tm_store_slice(C.byref(s), first, n, C.byref(out))
+        assert (rc == 0) == rc_ok, (first, n, rc)
+        if rc_ok:
+            assert out.n_games == n
+            gs0 = C.cast(s.gs, C.c_void_p).value or 0
+            gs1 = C.cast(out.gs, C.c_void_p).value or 0
+            assert gs1 - gs0 == first * 64 * 4          # the control blocks: 64 words a game
