@@ -135,3 +135,65 @@ def test_marker_with_the_bitmaps_in_memory(oracle, monkeypatch):
     monkeypatch.setenv("TM_GC_MARKS_IN_MEMORY", "1")
     assert _compare_run(oracle, "ValueSim", G=6, sims=40, max_nodes=8000, seed=11, moves=110, evaluator="hash", check_tree_every=25) >= 1
     assert _compare_run(oracle, "ValueSimLP", G=40, sims=30, max_nodes=6000, seed=5, moves=90, evaluator="hash", check_tree_every=30) >= 10
+
+
+def test_every_phase_word_has_its_summary_bit():
+    """The collectors find the collecting games through TM_GS_GC_ACTIVE4 (a bit a game in the control block of every fourth game)
+    instead of reading every game's phase word: a phase without its bit would never be served.  Launch by launch over a batch
+    whose small pools collect all the time (requests, speculative markings, collections under way, resumes, root moves that drop
+    markings, pools outgrown and reset): after every launch every non-zero phase word has its bit, and the native loop (two
+    sub-batches: slices of the store) keeps it so."""
+    from tetris_mcts_amd import store as st
+    from tetris_mcts_amd.model import Model_VV
+    G = 72
+    game, agent = _agent(G, 40, 1500, 7, model=Model_VV(backend="hip", seed=0), n_sub=1)
+    S = agent.store
+    both = st.SIM_BACKUP | st.SIM_FRONT
+    idx = torch.arange(G, device=S.device)
+
+    def check(where):
+        gs = S.t["gs"]
+        phase = gs[:, st.GS["GC_PHASE"]]
+        bit = (gs[(idx & ~3), st.GS["GC_ACTIVE4"]] >> (idx & 3)) & 1
+        bad = (phase != 0) & (bit == 0)
+        assert not bool(bad.any()), (where, torch.nonzero(bad).flatten().tolist(), phase[bad].tolist())
+        return int((phase != 0).sum())
+
+    seen = 0
+    for move in range(40):
+        S.move_begin(40)
+        S.sim_step(both)
+        for _ in range(40):
+            agent.evaluate_requests()
+            S.sim_step(both)
+            seen += check("launch of move %d" % move)
+        todo, collecting = S.sims_remaining()
+        while todo or collecting:
+            while collecting:
+                S.gc_step()
+                check("collector-only launch")
+                todo, collecting = S.sims_remaining()
+            for _ in range(todo):
+                agent.evaluate_requests()
+                S.sim_step(both)
+                check("catch-up launch")
+            todo, collecting = S.sims_remaining()
+        _, action = S.root_stats()
+        game.play(action.cpu().numpy())
+        agent.update_root(game)
+        check("update_root")
+        if np.atleast_1d(game.end).any():
+            game.reset("ended")
+            agent.update_root(game)
+    assert seen > 500 and int(S.t["gs"][:, st.GS["N_GC"]].sum()) > 100, (seen, int(S.t["gs"][:, st.GS["N_GC"]].sum()))
+    assert (S.errors().cpu().numpy() & ~1).max() == 0
+    # ... and through the native loop with two sub-batches (slices of 36 games)
+    for _ in range(12):
+        S.search(40, agent.model, n_sub=2)
+        check("native loop")
+        a = agent.get_action()
+        game.play(a)
+        agent.update_root(game)
+        if np.atleast_1d(game.end).any():
+            game.reset("ended")
+            agent.update_root(game)
