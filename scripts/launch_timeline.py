@@ -34,8 +34,10 @@ for m in range(a.warm_moves + a.moves):
         the = vals[np.argmax(cnt)]                # the move's last launch that starts a simulation for every game
         sel = launch == the
         s0, s1 = u("CYC_BACK")[sel], u("CYC_SELECT")[sel]
-        o = 2 * a.collectors * int(the & 1)       # (the collectors' stamps of even / odd launches are kept apart)
-        c0, c1, cl = u(34)[o:o + a.collectors], u(35)[o:o + a.collectors], u(34)[o + a.collectors:o + 2 * a.collectors]
+        o, nc = 3 * a.collectors * int(the & 1), a.collectors       # (the collectors' stamps of even / odd launches are kept apart;
+        c0, c1, cl = u(35)[o:o + nc], u(35)[o + nc:o + 2 * nc], u(35)[o + 2 * nc:o + 3 * nc]      #  the spare word 35: start, end, launch)
+        if ((c1 >> 16) != (the & 0xFFFF)).any(): cl = cl * 0 - 1      # (the end words carry their launch too)
+        c1 = c0 + (c1 & 0xFFFF)                    # end = start + ticks (kept relative: the 32-bit clock wraps every 43 s)
         if not (cl == the).all():
             print("move %d: the collectors' stamps are of launch %s, the simulation waves' of %d - skipped" % (m, np.unique(cl), the), flush=True)
             continue_ = True

@@ -2874,7 +2874,10 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_sim_step(tm_store S, int flags)
             const size_t row = (size_t)blockIdx.x + ((((unsigned)flags >> 8) & 1) ? 3 * n_gc : 0);
             if (w == 0) S.gs[row * TM_GS_DW + TM_GS_GC_RSV1] = (int)tl0;
             if (w == 0) S.gs[(row + 2 * n_gc) * TM_GS_DW + TM_GS_GC_RSV1] = (int)((unsigned)flags >> 8);
-            atomicMax(reinterpret_cast<unsigned*>(S.gs + (row + n_gc) * TM_GS_DW + TM_GS_GC_RSV1), (unsigned)__builtin_amdgcn_s_memrealtime());
+            // (the end as launch << 16 | ticks since the start, the largest over the workgroup's waves: grows from launch to launch
+            // whatever the 32-bit clock does - good for 65 535 launches)
+            const unsigned dt = (unsigned)__builtin_amdgcn_s_memrealtime() - tl0;
+            atomicMax(reinterpret_cast<unsigned*>(S.gs + (row + n_gc) * TM_GS_DW + TM_GS_GC_RSV1), ((((unsigned)flags >> 8) & 0xFFFFu) << 16) | (dt < 0xFFFFu ? dt : 0xFFFFu));
         }
 #endif
         return;
